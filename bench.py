@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the Smith-Waterman DP fill on MI355X (BASELINE.json metric).
+
+One "step" = one full DP fill (H and P matrices + arg-max) of one cols x rows random DNA pair whose
+sequences are already resident in HBM.  N=1 runs BASELINE config[1]: 16384 x 16384, int32 H/P.
+For N>1 (one process per GPU, launched by torch.distributed.run) every rank fills its own pair
+of the same size (weak scaling, no data-path collective); ranks synchronise only around the
+timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(cols, rows):
+    """Time the REAL reference (oracle/_ref, built from the reference's serial_smithW.c in the build
+    container) on this box's host cores; falls back to the C port (oracle/liboracle.so)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "serial_smithW")
+    out = {}
+    if os.path.exists(ref):
+        t = subprocess.run([ref, str(cols), str(rows)], capture_output=True, text=True, timeout=600).stdout
+        sec = float(re.search(r"scoring matrix computation:\s*([0-9.]+)", t).group(1))
+        out = {"value": cols * rows / sec / 1e9, "unit": "GCUPS", "cores": 1, "kind": "reference",
+               "sample": f"serial_smithW {cols} {rows} (the full workload, fill loop only), {sec:.3f} s"}
+        omp = os.path.join(ROOT, "oracle", "_ref", "omp_smithW-v1")
+        if os.path.exists(omp):
+            nthr = len(os.sched_getaffinity(0))
+            env = dict(os.environ, OMP_NUM_THREADS=str(nthr), OMP_PROC_BIND="close")
+            t = subprocess.run([omp, str(cols), str(rows)], capture_output=True, text=True, timeout=600, env=env).stdout
+            m = re.search(r"scoring matrix computation:\s*([0-9.]+)", t)
+            if m:
+                out["omp"] = {"value": cols * rows / float(m.group(1)) / 1e9, "unit": "GCUPS", "cores": nthr,
+                              "kind": "reference",
+                              "sample": f"omp_smithW-v1-refinedOrig -DSKIP_BACKTRACK {cols} {rows}, {float(m.group(1)):.3f} s"}
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        orc = oracle_lib.Oracle()
+        a, b = orc.generate(cols, rows, 1)
+        t0 = time.time()
+        orc.fill_streaming(a, b)
+        sec = time.time() - t0
+        out = {"value": cols * rows / sec / 1e9, "unit": "GCUPS", "cores": 1, "kind": "port",
+               "sample": f"oracle streaming fill {cols}x{rows}, {sec:.3f} s"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cols", type=int, default=16384)
+    ap.add_argument("--rows", type=int, default=16384)
+    ap.add_argument("--h64", action="store_true", help="int64 H (BASELINE config 3 element type)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--wpb", type=int, default=0)
+    ap.add_argument("--max-blocks", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    sw = importlib.import_module("smith-waterman_amd")
+    eng = sw.Engine(local)
+    if args.wpb:
+        eng.set_option("waves_per_block", args.wpb)
+    if args.max_blocks:
+        eng.set_option("max_blocks", args.max_blocks)
+
+    cols, rows = args.cols, args.rows
+    a, b = sw.generate(cols, rows, 1 + rank)          # reference generator; rank r uses seed 1+r
+    d_a, _ = eng.to_device(a)
+    d_b, _ = eng.to_device(b)
+    out = eng.alloc(cols, rows, torch.int64 if args.h64 else torch.int32)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.fill_into(out, d_a, d_b)
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record()
+        eng.fill_into(out, d_a, d_b)
+        e1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    res = out.result()
+    kern_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+    if world > 1:
+        tmax = torch.tensor([dt], device=f"cuda:{local}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        cells = cols * rows
+        bytes_per_cell = 12 if args.h64 else 8       # mandatory H + P output only
+        avg_ms = sum(kern_ms) / len(kern_ms)
+        achieved = bytes_per_cell * cells / (avg_ms * 1e-3) / 1e9
+        line = {
+            "metric": "GCUPS (DP cell updates/s) on NxN random DNA pair", "value": world * args.steps * cells / dt / 1e9,
+            "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64" if args.h64 else "int32", "data": "synthetic",
+            "config": {"workload": f"{cols}x{rows} random DNA pair (reference generator, seed 1+rank), linear gap 3/-3/-2, "
+                                   f"{'int64' if args.h64 else 'int32'} H + int32 P written to HBM, arg-max tracked",
+                       "per_gpu": "one independent pair per GPU", "max_pos": res["max_pos"], "max_score": res["max_score"],
+                       "grid": eng.get_option("last_grid"), "strips": eng.get_option("last_strips")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
+                         "algorithmic_bytes_per_cell": bytes_per_cell},
+        }
+        if not args.no_cpu and world == 1:
+            cb = cpu_baseline(cols, rows)
+            omp = cb.pop("omp", None)
+            line["cpu_baseline"] = cb
+            if omp:
+                line["cpu_baseline_omp"] = omp
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

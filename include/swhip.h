@@ -1,0 +1,116 @@
+/*
+ * swhip.h -- C-ABI of the MI355X-native Smith-Waterman DP-fill engine (libswhip.so).
+ *
+ * Drop-in boundary for the reference's hot path.  The reference has no
+ * FFI; each entry point below names the reference code it replaces (paths relative to the
+ * reference repository root).  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SW_E* code on failure, never exit()s
+ *     (the reference's CUDA path prints and exit(0)s, simple-cuda/sw-default-discrete.cu:101-108);
+ *     sw_last_error() returns a thread-local description of the last failure.
+ *   - cols = len(a) = matrix columns, rows = len(b) = matrix rows (serial_smithW.c:72-77);
+ *     H and P are (rows+1) x (cols+1), row-major, row stride cols+1 (serial_smithW.c:192).
+ *   - "d_" pointers are DEVICE (HBM) pointers, everything else is host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ */
+#ifndef SWHIP_H
+#define SWHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SW_OK 0
+#define SW_EINVAL (-22)   /* bad argument */
+#define SW_ENOMEM (-12)   /* host or device allocation failed */
+#define SW_EDEVICE (-5)   /* HIP runtime error */
+#define SW_ETIMEOUT (-62) /* an in-kernel hand-off wait gave up (never expected) */
+#define SW_ENODEV (-19)   /* no usable GPU */
+
+/* predecessor codes, serial_smithW.c:23-27 */
+#define SW_PATH (-1)
+#define SW_NONE 0
+#define SW_UP 1
+#define SW_LEFT 2
+#define SW_DIAGONAL 3
+
+/* serial_smithW.c:59-61 (matchScore, missmatchScore, gapScore); default {3,-3,-2}. gap must be <= 0. */
+typedef struct { int32_t match, mismatch, gap; } sw_scores;
+
+/* max_pos: linear index rows-major of the arg-max cell, lowest index among ties, 0 if H == 0
+ * everywhere (what the scan at serial_smithW.c:240-242 yields); max_score = H[max_pos];
+ * path_len: cells negated by the traceback (0 until a traceback ran). */
+typedef struct { int64_t max_pos; int64_t max_score; int64_t path_len; } sw_result;
+
+typedef struct sw_ctx sw_ctx; /* one per GPU; one host thread drives a ctx at a time */
+
+const char* sw_last_error(void);
+const char* sw_version(void);
+
+/* ---- input side ---------------------------------------------------------------------------
+ * sw_generate: replaces generate(), serial_smithW.c:334-361, bit-exact incl. its draw order
+ * (cols+1 rand() draws for a, then rows+1 for b; glibc TYPE_3 rand() restated, no libc state).
+ * seed 1 == serial_smithW.c (which never calls srand).  a holds cols+1 bytes, b rows+1. */
+int sw_generate(int64_t cols, int64_t rows, uint32_t seed, char* a, char* b);
+
+/* ---- wavefront indexing: nElement / calcFirstDiagElement, omp_smithW.c:260-275, 282-291.
+ * m, n are the padded sizes (cols+1, rows+1); i in [1, m+n-3]. */
+int64_t sw_nelement(int64_t i, int64_t m, int64_t n);
+void sw_first_diag_element(int64_t i, int64_t m, int64_t n, int64_t* si, int64_t* sj);
+
+/* ---- context ------------------------------------------------------------------------------ */
+int sw_create(int device, sw_ctx** out);
+void sw_destroy(sw_ctx* ctx);
+
+/* ---- the hot path ---------------------------------------------------------------------------
+ * sw_fill_device: replaces the fill loop + similarityScore/matchMissmatchScore
+ * (serial_smithW.c:141-145, 187-256; omp_smithW.c:203-216) and the rotated family's
+ * smithWaterman(a,b,w,h,H,P,&maxloc) (rotated-cuda/sw-rotated-omp.cc:192-209).
+ * Asynchronous on `stream`.  d_H/d_P need not be initialised (row 0 / column 0 are written).
+ *   h_elem_bytes : 4 -> d_H is int32_t*, 8 -> d_H is int64_t* (same values, widened)
+ *   d_top        : optional (may be NULL) int32 H values of the row above this band, cols+1
+ *                  entries (multi-GPU row bands); NULL == zeros (a whole matrix)
+ *   d_result     : device sw_result; max_pos/max_score valid when the stream has drained */
+int sw_fill_device(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, int64_t rows,
+                   const sw_scores* scores, void* d_H, int h_elem_bytes, int32_t* d_P,
+                   const int32_t* d_top, sw_result* d_result, void* stream);
+
+/* Host-buffer convenience wrapper around sw_fill_device (alloc, H2D, fill, D2H, sync).
+ * H, P: caller-owned int32 (rows+1)*(cols+1); either may be NULL to skip its copy-out. */
+int sw_fill_host(sw_ctx* ctx, const char* a, int64_t cols, const char* b, int64_t rows,
+                 const sw_scores* scores, int32_t* H, int32_t* P, sw_result* result);
+
+/* ---- traceback: replaces backtrack(), serial_smithW.c:262-277.  Negates P along the path.
+ * d_path (optional) receives the visited linear indices (capacity path_cap);
+ * d_result->path_len is set.  P[max_pos]==NONE (UB in the reference) == empty path. */
+int sw_traceback_device(sw_ctx* ctx, int32_t* d_P, int64_t cols, int64_t rows, int64_t max_pos,
+                        int64_t* d_path, int64_t path_cap, sw_result* d_result, void* stream);
+int sw_traceback_host(int32_t* P, int64_t cols, int64_t rows, int64_t max_pos,
+                      int64_t* path, int64_t path_cap, int64_t* path_len);
+
+/* ---- verification helpers (not on the timed path) ------------------------------------------
+ * Position-weighted row checksums of a device matrix with (rows1 x m) elements:
+ *   cs[i] = sum_j (uint64)(uint32)X[i][j] * ((j+1) * 0x9E3779B97F4A7C15)  (mod 2^64)
+ * elem_bytes 4 or 8 (8: low 32 bits are summed and the high half must be the sign extension,
+ * otherwise cs[i] is forced to ~0). d_cs: rows1 uint64 on the device. */
+int sw_row_checksums_device(sw_ctx* ctx, const void* d_X, int elem_bytes, int64_t rows1, int64_t m,
+                            uint64_t* d_cs, void* stream);
+
+/* ---- device memory plumbing for hosts without a HIP binding (cgo / JNI / ctypes callers) --- */
+int sw_device_malloc(sw_ctx* ctx, size_t bytes, void** d_ptr);
+int sw_device_free(sw_ctx* ctx, void* d_ptr);
+int sw_memcpy_h2d(sw_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int sw_memcpy_d2h(sw_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports kernel faults */
+
+/* ---- tuning knobs (0 = built-in default) -------------------------------------------------- */
+int sw_set_option(sw_ctx* ctx, const char* name, int64_t value);
+int64_t sw_get_option(sw_ctx* ctx, const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

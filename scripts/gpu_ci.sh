@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): parity tests, smoke, a short bench, and a rocprofv3 kernel trace.
+# A step that times out / is killed stops the chain (no further GPU work after a hang).
+set -u
+mkdir -p gpurun_out
+step() {  # step <name> <timeout_s> <cmd...>
+    local name=$1 to=$2; shift 2
+    echo "=== $name" | tee -a gpurun_out/ci.log
+    timeout -k 10 "$to" "$@" > "gpurun_out/$name.log" 2>&1
+    local rc=$?
+    echo "$name rc=$rc" | tee -a gpurun_out/ci.log
+    tail -n 15 "gpurun_out/$name.log"
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a gpurun_out/ci.log; exit 1; fi
+    return 0
+}
+: > gpurun_out/ci.log
+rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 >> gpurun_out/ci.log
+nproc >> gpurun_out/ci.log; lscpu | grep "Model name" >> gpurun_out/ci.log
+step smoke 300 python __graft_entry__.py smoke
+step pytest_gpu 600 python -m pytest tests -m gpu -x -q
+step bench 400 python bench.py --steps 10 --warmup 2
+export TMPDIR=/tmp
+step rocprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 5 --warmup 1 --no-cpu
+find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -8 "$f"; done

@@ -1,0 +1,249 @@
+"""smith-waterman_amd -- host-side mirror (ctypes) of the C-ABI in include/swhip.h.
+
+The product is libswhip.so (hand-written gfx950 HIP kernels + a C-ABI); this module is plumbing
+for tests / bench / Python callers: torch provides device memory and streams only.  There is NO
+CPU fallback: if libswhip.so is missing, importing the library handle raises.
+
+Names follow the reference (paths relative to the reference repository):
+  generate()            serial_smithW.c:334-361
+  Engine.fill()         fill loop + similarityScore, serial_smithW.c:141-145,187-256;
+                        smithWaterman(a,b,w,h,H,P,&maxloc), rotated-cuda/sw-rotated-omp.cc:192-209
+  Engine.traceback()    backtrack(), serial_smithW.c:262-277
+  n_element / first_diag_element    omp_smithW.c:260-291
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswhip.so")
+
+NONE, UP, LEFT, DIAGONAL, PATH = 0, 1, 2, 3, -1
+DEFAULT_SCORES = (3, -3, -2)  # serial_smithW.c:59-61
+
+
+class SwError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"swhip error {code}: {msg}")
+        self.code = code
+
+
+class _Scores(ctypes.Structure):
+    _fields_ = [("match", ctypes.c_int32), ("mismatch", ctypes.c_int32), ("gap", ctypes.c_int32)]
+
+
+class _Result(ctypes.Structure):
+    _fields_ = [("max_pos", ctypes.c_int64), ("max_score", ctypes.c_int64), ("path_len", ctypes.c_int64)]
+
+
+# every symbol include/swhip.h declares: (restype, argtypes)
+_vp, _i64, _i32, _u32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32, ctypes.c_size_t
+ABI = {
+    "sw_last_error": (ctypes.c_char_p, []),
+    "sw_version": (ctypes.c_char_p, []),
+    "sw_generate": (_i32, [_i64, _i64, _u32, _vp, _vp]),
+    "sw_nelement": (_i64, [_i64, _i64, _i64]),
+    "sw_first_diag_element": (None, [_i64, _i64, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "sw_create": (_i32, [_i32, ctypes.POINTER(_vp)]),
+    "sw_destroy": (None, [_vp]),
+    "sw_fill_device": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _i32, _vp, _vp, _vp, _vp]),
+    "sw_fill_host": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result)]),
+    "sw_traceback_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "sw_traceback_host": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
+    "sw_row_checksums_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
+    "sw_device_malloc": (_i32, [_vp, _sz, ctypes.POINTER(_vp)]),
+    "sw_device_free": (_i32, [_vp, _vp]),
+    "sw_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),
+    "sw_memcpy_d2h": (_i32, [_vp, _vp, _vp, _sz]),
+    "sw_synchronize": (_i32, [_vp, _vp]),
+    "sw_set_option": (_i32, [_vp, ctypes.c_char_p, _i64]),
+    "sw_get_option": (_i64, [_vp, ctypes.c_char_p]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libswhip.so (built in-tree by `make -C smith-waterman_amd`). Fails loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not built: run `make -C {_HERE}` (hipcc --offload-arch=gfx950); "
+                              "there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in ABI.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise SwError(rc, lib().sw_last_error().decode())
+
+
+def generate(cols: int, rows: int, seed: int = 1):
+    """Random DNA pair exactly as the reference's generate() (seed 1 == serial_smithW.c).
+    Returns (a, b) as uint8 arrays of length cols / rows."""
+    a = np.zeros(cols + 1, np.uint8)
+    b = np.zeros(rows + 1, np.uint8)
+    _check(lib().sw_generate(cols, rows, seed, a.ctypes.data, b.ctypes.data))
+    return a[:cols].copy(), b[:rows].copy()
+
+
+def n_element(i: int, m: int, n: int) -> int:
+    return int(lib().sw_nelement(i, m, n))
+
+
+def first_diag_element(i: int, m: int, n: int):
+    si, sj = _i64(), _i64()
+    lib().sw_first_diag_element(i, m, n, ctypes.byref(si), ctypes.byref(sj))
+    return int(si.value), int(sj.value)
+
+
+def traceback_host(P: np.ndarray, max_pos: int):
+    """backtrack() on a host int32 P (modified in place). Returns the visited linear indices."""
+    rows1, m = P.shape
+    assert P.dtype == np.int32 and P.flags.c_contiguous
+    path = np.zeros(rows1 + m + 2, np.int64)
+    n = _i64()
+    _check(lib().sw_traceback_host(P.ctypes.data, m - 1, rows1 - 1, int(max_pos), path.ctypes.data, len(path), ctypes.byref(n)))
+    return path[: n.value].copy()
+
+
+def _as_seq(x) -> np.ndarray:
+    if isinstance(x, (bytes, bytearray)):
+        return np.frombuffer(bytes(x), np.uint8)
+    if isinstance(x, str):
+        return np.frombuffer(x.encode(), np.uint8)
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+@dataclass
+class Fill:
+    """Device-resident result of one DP fill. H: (rows+1, cols+1) int32|int64, P: int32, both torch
+    CUDA tensors; res: int64[3] tensor (max_pos, max_score, path_len)."""
+    H: "torch.Tensor"
+    P: "torch.Tensor"
+    res: "torch.Tensor"
+    cols: int
+    rows: int
+
+    def result(self):
+        r = self.res.cpu().tolist()
+        if r[2] < 0:
+            raise SwError(-62, "in-kernel hand-off wait timed out")
+        return {"max_pos": r[0], "max_score": r[1], "path_len": r[2]}
+
+
+class Engine:
+    """One GPU's fill engine (sw_ctx). Uses torch only for device buffers / current stream."""
+
+    def __init__(self, device: int = 0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("smith-waterman_amd.Engine needs a GPU (no CPU fallback exists)")
+        self.torch = torch
+        self.device = device
+        torch.cuda.set_device(device)
+        h = _vp()
+        _check(lib().sw_create(device, ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sw_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_option(self, name: str, value: int):
+        _check(lib().sw_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        return int(lib().sw_get_option(self._h, name.encode()))
+
+    def _stream(self):
+        return _vp(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def to_device(self, seq):
+        """Sequence -> padded uint8 device tensor (16 spare bytes; the kernel reads b in 16-B windows)."""
+        t = self.torch
+        s = _as_seq(seq)
+        d = t.zeros(len(s) + 16, dtype=t.uint8, device=f"cuda:{self.device}")
+        if len(s):
+            d[: len(s)] = t.from_numpy(s.copy())
+        return d, len(s)
+
+    def alloc(self, cols: int, rows: int, h_dtype=None):
+        t = self.torch
+        h_dtype = h_dtype or t.int32
+        dev = f"cuda:{self.device}"
+        H = t.empty((rows + 1, cols + 1), dtype=h_dtype, device=dev)
+        P = t.empty((rows + 1, cols + 1), dtype=t.int32, device=dev)
+        res = t.zeros(3, dtype=t.int64, device=dev)
+        return Fill(H, P, res, cols, rows)
+
+    def fill_into(self, out: Fill, d_a, d_b, scores=DEFAULT_SCORES, top=None):
+        """Asynchronous fill on torch's current stream into pre-allocated buffers."""
+        t = self.torch
+        sc = _Scores(*scores)
+        hb = 8 if out.H.dtype == t.int64 else 4
+        _check(lib().sw_fill_device(self._h, d_a.data_ptr(), out.cols, d_b.data_ptr(), out.rows, ctypes.byref(sc),
+                                    out.H.data_ptr(), hb, out.P.data_ptr(),
+                                    top.data_ptr() if top is not None else None, out.res.data_ptr(), self._stream()))
+        return out
+
+    def fill(self, a, b, scores=DEFAULT_SCORES, h_dtype=None, top=None) -> Fill:
+        d_a, cols = self.to_device(a)
+        d_b, rows = self.to_device(b)
+        out = self.alloc(cols, rows, h_dtype)
+        if top is not None:
+            top = self.torch.as_tensor(np.ascontiguousarray(top, np.int32)).to(f"cuda:{self.device}")
+        self.fill_into(out, d_a, d_b, scores, top)
+        self.synchronize()
+        return out
+
+    def traceback(self, out: Fill, max_pos: int | None = None, want_path: bool = True):
+        """backtrack() on the device P (negates the path in place). Returns the path indices."""
+        t = self.torch
+        if max_pos is None:
+            max_pos = out.result()["max_pos"]
+        cap = out.cols + out.rows + 2
+        path = t.zeros(cap if want_path else 1, dtype=t.int64, device=out.P.device)
+        _check(lib().sw_traceback_device(self._h, out.P.data_ptr(), out.cols, out.rows, int(max_pos),
+                                         path.data_ptr() if want_path else None, cap, out.res.data_ptr(), self._stream()))
+        self.synchronize()
+        n = int(out.res[2].item())
+        return path[:n].cpu().numpy() if want_path else n
+
+    def row_checksums(self, X):
+        t = self.torch
+        cs = t.zeros(X.shape[0], dtype=t.int64, device=X.device)
+        _check(lib().sw_row_checksums_device(self._h, X.data_ptr(), X.element_size(), X.shape[0], X.shape[1],
+                                             cs.data_ptr(), self._stream()))
+        self.synchronize()
+        return cs.cpu().numpy().view(np.uint64)
+
+    def synchronize(self):
+        _check(lib().sw_synchronize(self._h, self._stream()))
+
+
+def smith_waterman(a, b, scores=DEFAULT_SCORES, device: int = 0, backtrack: bool = True):
+    """Whole-pipeline convenience with host arrays, shaped like the reference's program:
+    returns dict(H, P, max_pos, max_score, path) with P negated along the path when backtrack."""
+    eng = Engine(device)
+    try:
+        out = eng.fill(a, b, scores)
+        r = out.result()
+        path = eng.traceback(out, r["max_pos"]) if backtrack else np.zeros(0, np.int64)
+        return {"H": out.H.cpu().numpy(), "P": out.P.cpu().numpy(), "max_pos": r["max_pos"],
+                "max_score": r["max_score"], "path": path}
+    finally:
+        eng.close()

@@ -1,0 +1,131 @@
+// smithW -- host driver with the reference's command line (serial_smithW.c:71-180, omp_smithW.c:87-253):
+//   smithW                  built-in 8x9 example (serial_smithW.c:105-125) + its known-answer checks
+//   smithW <cols> <rows>    random DNA pair from the reference generator (seed 1 == serial_smithW.c)
+// Extra flags (after the positional ones): --seed N  --dump  --h64  --no-backtrack  --scores M X G
+// The DP fill runs on the GPU through the C-ABI (include/swhip.h); stdout keeps the two
+// "Elapsed time ..." lines the reference's run scripts grep for (readme.liao:12).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/swhip.h"
+
+#define RESET "\033[0m"
+#define BOLDRED "\033[1m\033[31m"
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#define CHECK(call)                                                              \
+    do {                                                                         \
+        int rc_ = (call);                                                        \
+        if (rc_ != SW_OK) {                                                      \
+            fprintf(stderr, "smithW: %s -> %d: %s\n", #call, rc_, sw_last_error()); \
+            return 1;                                                            \
+        }                                                                        \
+    } while (0)
+
+// printMatrix / printPredecessorMatrix, serial_smithW.c:283-328
+static void print_matrix(const std::vector<int32_t>& H, long long n, long long m) {
+    for (long long i = 0; i < n; i++) {
+        for (long long j = 0; j < m; j++) printf("%d\t", H[m * i + j]);
+        printf("\n");
+    }
+}
+static void print_pred(const std::vector<int32_t>& P, long long n, long long m) {
+    for (long long i = 0; i < n; i++) {
+        for (long long j = 0; j < m; j++) {
+            const int v = P[m * i + j], av = v < 0 ? -v : v;
+            const char* sym = av == SW_UP ? "↑ " : av == SW_LEFT ? "← " : av == SW_DIAGONAL ? "↖ " : "- ";
+            if (v < 0) printf(BOLDRED "%s" RESET, sym); else printf("%s", sym);
+        }
+        printf("\n");
+    }
+}
+
+int main(int argc, char** argv) {
+    long long cols = 8, rows = 9;
+    bool builtin = true, dump = false, h64 = false, backtrack = true;
+    unsigned seed = 1;
+    sw_scores sc = {3, -3, -2};
+    int ai = 1;
+    if (argc >= 3 && argv[1][0] != '-' && argv[2][0] != '-') {
+        cols = strtoll(argv[1], nullptr, 10);
+        rows = strtoll(argv[2], nullptr, 10);
+        builtin = false;
+        ai = 3;
+    }
+    for (; ai < argc; ++ai) {
+        std::string f = argv[ai];
+        if (f == "--dump") dump = true;
+        else if (f == "--h64") h64 = true;
+        else if (f == "--no-backtrack") backtrack = false;
+        else if (f == "--seed" && ai + 1 < argc) seed = (unsigned)strtoul(argv[++ai], nullptr, 10);
+        else if (f == "--scores" && ai + 3 < argc) { sc.match = atoi(argv[++ai]); sc.mismatch = atoi(argv[++ai]); sc.gap = atoi(argv[++ai]); }
+        else { fprintf(stderr, "usage: smithW [<cols> <rows>] [--seed N] [--dump] [--h64] [--no-backtrack] [--scores M X G]\n"); return 2; }
+    }
+    const long long m = cols + 1, n = rows + 1;
+    std::vector<char> a(m + 1), b(n + 1);
+    if (builtin) { memcpy(b.data(), "GGTTGACTA", 9); memcpy(a.data(), "TGTTACGG", 8); }
+    else CHECK(sw_generate(cols, rows, seed, a.data(), b.data()));
+    if (dump) { if (builtin) printf("\n Using built-in data for testing .."); printf("\nMatrix[%lld][%lld]\n", rows, cols); }
+
+    sw_ctx* ctx = nullptr;
+    CHECK(sw_create(0, &ctx));
+    const size_t cells = (size_t)m * (size_t)n;
+    void *d_a, *d_b, *d_H, *d_P, *d_res;
+    CHECK(sw_device_malloc(ctx, (size_t)cols + 16, &d_a));
+    CHECK(sw_device_malloc(ctx, (size_t)rows + 16, &d_b));
+    CHECK(sw_device_malloc(ctx, cells * (h64 ? 8 : 4), &d_H));
+    CHECK(sw_device_malloc(ctx, cells * 4, &d_P));
+    CHECK(sw_device_malloc(ctx, sizeof(sw_result), &d_res));
+    CHECK(sw_memcpy_h2d(ctx, d_a, a.data(), (size_t)cols));
+    CHECK(sw_memcpy_h2d(ctx, d_b, b.data(), (size_t)rows));
+    // one untimed call sizes the workspace (the reference's timer also excludes its allocations)
+    CHECK(sw_fill_device(ctx, (const char*)d_a, cols, (const char*)d_b, rows, &sc, d_H, h64 ? 8 : 4, (int32_t*)d_P, nullptr, (sw_result*)d_res, nullptr));
+    CHECK(sw_synchronize(ctx, nullptr));
+
+    double t0 = now_s();
+    CHECK(sw_fill_device(ctx, (const char*)d_a, cols, (const char*)d_b, rows, &sc, d_H, h64 ? 8 : 4, (int32_t*)d_P, nullptr, (sw_result*)d_res, nullptr));
+    CHECK(sw_synchronize(ctx, nullptr));
+    double t1 = now_s();
+    printf("\nElapsed time for scoring matrix computation: %f\n\n", t1 - t0);
+    sw_result res;
+    CHECK(sw_memcpy_d2h(ctx, &res, d_res, sizeof res));
+    if (res.path_len < 0) { fprintf(stderr, "smithW: device hand-off timed out\n"); return 1; }
+
+    t0 = now_s();
+    if (backtrack) {
+        CHECK(sw_traceback_device(ctx, (int32_t*)d_P, cols, rows, res.max_pos, nullptr, 0, (sw_result*)d_res, nullptr));
+        CHECK(sw_synchronize(ctx, nullptr));
+        CHECK(sw_memcpy_d2h(ctx, &res, d_res, sizeof res));
+    }
+    t1 = now_s();
+    printf("\nElapsed time for backtracking: %f\n\n", t1 - t0);
+    printf("maxPos = %lld, H[maxPos] = %lld, path length = %lld\n", (long long)res.max_pos,
+           (long long)res.max_score, (long long)res.path_len);
+
+    int rc = 0;
+    if (dump || builtin) {
+        std::vector<int32_t> H(cells), P(cells);
+        if (h64) {
+            std::vector<int64_t> H8(cells);
+            CHECK(sw_memcpy_d2h(ctx, H8.data(), d_H, cells * 8));
+            for (size_t k = 0; k < cells; ++k) H[k] = (int32_t)H8[k];
+        } else CHECK(sw_memcpy_d2h(ctx, H.data(), d_H, cells * 4));
+        CHECK(sw_memcpy_d2h(ctx, P.data(), d_P, cells * 4));
+        if (dump) { printf("\nSimilarity Matrix:\n"); print_matrix(H, n, m); }
+        if (builtin) {
+            // the reference's built-in checks: serial_smithW.c:162-166, omp_smithW-v1-refinedOrig.cpp:229-238
+            const bool ok = H[m * n - 1] == 7 && res.max_pos == 69 && res.max_score == 13;
+            printf("Verifying correctness using builtin data =%d\n", ok);
+            if (!ok) rc = 1;
+        }
+        if (dump) { printf("\nPredecessor Matrix:\n"); print_pred(P, n, m); }
+    }
+    sw_device_free(ctx, d_a); sw_device_free(ctx, d_b); sw_device_free(ctx, d_H); sw_device_free(ctx, d_P); sw_device_free(ctx, d_res);
+    sw_destroy(ctx);
+    return rc;
+}

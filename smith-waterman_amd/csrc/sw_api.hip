@@ -1,0 +1,251 @@
+// sw_api.hip -- C-ABI entry points that drive the HIP kernels (see include/swhip.h).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "sw_kernels.h"
+
+namespace swh { void set_err(const char* fmt, ...); }
+using swh::set_err;
+
+#define HIP_TRY(expr)                                                                 \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SW_EDEVICE;                                                        \
+        }                                                                             \
+    } while (0)
+
+struct sw_ctx {
+    int device = 0;
+    int num_cus = 256;
+    unsigned epoch = 0;                 // 12-bit launch tag, see FillParams::tag_base
+    unsigned long long* d_edge = nullptr;
+    size_t edge_cap = 0;                // granules
+    unsigned long long* d_key = nullptr; // [0] = arg-max key, [1] low word = abort flag
+    int64_t opt_waves_per_block = 4;
+    int64_t opt_max_blocks = 0;         // 0 -> 2 * CUs
+    int64_t last_grid = 0, last_strips = 0;
+};
+
+extern "C" {
+
+int sw_create(int device, sw_ctx** out) {
+    if (!out) { set_err("sw_create: out is NULL"); return SW_EINVAL; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_err("sw_create: no HIP device"); return SW_ENODEV; }
+    if (device < 0 || device >= n) { set_err("sw_create: device %d out of range (%d)", device, n); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(device));
+    sw_ctx* c = new sw_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount;
+    HIP_TRY(hipMalloc((void**)&c->d_key, 64));
+    HIP_TRY(hipMemset(c->d_key, 0, 64));
+    *out = c;
+    return SW_OK;
+}
+
+void sw_destroy(sw_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_edge) (void)hipFree(c->d_edge);
+    if (c->d_key) (void)hipFree(c->d_key);
+    delete c;
+}
+
+int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
+    if (!c || !name) { set_err("sw_set_option: bad argument"); return SW_EINVAL; }
+    if (!strcmp(name, "waves_per_block")) {
+        if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8 && v != 16) { set_err("waves_per_block must be 1,2,4,8,16"); return SW_EINVAL; }
+        c->opt_waves_per_block = v ? v : 4;
+        return SW_OK;
+    }
+    if (!strcmp(name, "max_blocks")) { c->opt_max_blocks = v < 0 ? 0 : v; return SW_OK; }
+    set_err("sw_set_option: unknown option '%s'", name);
+    return SW_EINVAL;
+}
+
+int64_t sw_get_option(sw_ctx* c, const char* name) {
+    if (!c || !name) return -1;
+    if (!strcmp(name, "waves_per_block")) return c->opt_waves_per_block;
+    if (!strcmp(name, "max_blocks")) return c->opt_max_blocks;
+    if (!strcmp(name, "num_cus")) return c->num_cus;
+    if (!strcmp(name, "last_grid")) return c->last_grid;
+    if (!strcmp(name, "last_strips")) return c->last_strips;
+    return -1;
+}
+
+static int check_dims(int64_t cols, int64_t rows, const sw_scores* sc) {
+    if (cols < 0 || rows < 0 || cols > swk::SW_MAX_DIM || rows > swk::SW_MAX_DIM) {
+        set_err("dimensions out of range: cols=%lld rows=%lld (max %lld)", (long long)cols, (long long)rows,
+                (long long)swk::SW_MAX_DIM);
+        return SW_EINVAL;
+    }
+    if (sc->gap > 0) { set_err("gap score must be <= 0 (got %d)", sc->gap); return SW_EINVAL; }
+    if (sc->match < 0) { set_err("match score must be >= 0 (got %d)", sc->match); return SW_EINVAL; }
+    const int64_t lo = std::min(cols, rows);
+    const int64_t gmax = (int64_t)sc->match * lo + (int64_t)(-sc->gap) * (rows + cols + 2);
+    if (gmax >= (1ll << 31) || (int64_t)sc->match * lo >= (1ll << 24)) {
+        set_err("scores too large for this problem size (32-bit cell / 24-bit arg-max key)");
+        return SW_EINVAL;
+    }
+    return SW_OK;
+}
+
+int sw_fill_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
+                   void* d_H, int h_elem_bytes, int32_t* d_P, const int32_t* d_top, sw_result* d_result, void* stream_) {
+    static const sw_scores kDefault = {3, -3, -2};  // serial_smithW.c:59-61
+    const sw_scores* sc = scores ? scores : &kDefault;
+    if (!c || !d_H || !d_P || !d_result || (h_elem_bytes != 4 && h_elem_bytes != 8)) {
+        set_err("sw_fill_device: bad argument");
+        return SW_EINVAL;
+    }
+    if (int rc = check_dims(cols, rows, sc)) return rc;
+    if ((cols > 0 && !d_a) || (rows > 0 && !d_b)) { set_err("sw_fill_device: NULL sequence"); return SW_EINVAL; }
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t M = cols + 1;
+    HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream));
+    if (cols == 0 || rows == 0) {
+        // no interior cell: H (= halo row / zero column) and P are all boundary
+        HIP_TRY(hipMemsetAsync(d_H, 0, (size_t)(M * (rows + 1)) * h_elem_bytes, stream));
+        HIP_TRY(hipMemsetAsync(d_P, 0, (size_t)(M * (rows + 1)) * 4, stream));
+        if (d_top && h_elem_bytes == 4) HIP_TRY(hipMemcpyAsync(d_H, d_top, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
+        if (d_top && h_elem_bytes == 8) { set_err("sw_fill_device: top halo with an empty int64 band is unsupported"); return SW_EINVAL; }
+    } else {
+        const int64_t S = (cols + 63) / 64;
+        const size_t need = (size_t)S * (size_t)(rows + 1);
+        if (need > c->edge_cap) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (c->d_edge) HIP_TRY(hipFree(c->d_edge));
+            c->d_edge = nullptr; c->edge_cap = 0;
+            if (hipMalloc((void**)&c->d_edge, need * 8) != hipSuccess) { set_err("workspace allocation of %zu bytes failed", need * 8); return SW_ENOMEM; }
+            c->edge_cap = need;
+            HIP_TRY(hipMemsetAsync(c->d_edge, 0, need * 8, stream));
+            c->epoch = 0;
+        }
+        if (++c->epoch >= 4096) {  // 12-bit tag wrapped: stale tags could match again, wipe them
+            HIP_TRY(hipMemsetAsync(c->d_edge, 0, c->edge_cap * 8, stream));
+            c->epoch = 1;
+        }
+        swk::FillParams p;
+        p.cols = cols; p.rows = rows; p.M = M;
+        p.H = d_H; p.P = d_P; p.top = d_top;
+        p.mm = sc->match - 2 * sc->gap; p.xm = sc->mismatch - 2 * sc->gap; p.ngap = -sc->gap;
+        p.edge = c->d_edge; p.tag_base = c->epoch << 20;
+        p.result_key = c->d_key; p.abort_flag = (unsigned int*)(c->d_key + 1);
+        p.nstrips = (int)S;
+        const int wpb = (int)c->opt_waves_per_block;
+        const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : 2ll * c->num_cus;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + wpb - 1) / wpb, maxb));
+        c->last_grid = grid; c->last_strips = S;
+        const unsigned char* ua = (const unsigned char*)d_a;
+        const unsigned char* ub = (const unsigned char*)d_b;
+        if (h_elem_bytes == 4)
+            hipLaunchKernelGGL((swk::sw_strip_scan<int32_t, 16>), dim3(grid), dim3(64 * wpb), 0, stream, ua, ub, p);
+        else
+            hipLaunchKernelGGL((swk::sw_strip_scan<int64_t, 16>), dim3(grid), dim3(64 * wpb), 0, stream, ua, ub, p);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(swk::sw_finalize, dim3(1), dim3(64), 0, stream, c->d_key, (const unsigned int*)(c->d_key + 1), d_result);
+    HIP_TRY(hipGetLastError());
+    return SW_OK;
+}
+
+int sw_fill_host(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t rows, const sw_scores* scores,
+                 int32_t* H, int32_t* P, sw_result* result) {
+    if (!c || !result) { set_err("sw_fill_host: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t cells = (size_t)(cols + 1) * (size_t)(rows + 1);
+    char *d_a = nullptr, *d_b = nullptr; int32_t *d_H = nullptr, *d_P = nullptr; sw_result* d_r = nullptr;
+    int rc = SW_OK;
+    auto cleanup = [&]() { (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_H); (void)hipFree(d_P); (void)hipFree(d_r); };
+    if (hipMalloc((void**)&d_a, (size_t)cols + 16) != hipSuccess || hipMalloc((void**)&d_b, (size_t)rows + 16) != hipSuccess ||
+        hipMalloc((void**)&d_H, cells * 4) != hipSuccess || hipMalloc((void**)&d_P, cells * 4) != hipSuccess ||
+        hipMalloc((void**)&d_r, sizeof(sw_result)) != hipSuccess) {
+        cleanup(); set_err("sw_fill_host: device allocation failed"); return SW_ENOMEM;
+    }
+    if (cols) (void)hipMemcpy(d_a, a, (size_t)cols, hipMemcpyHostToDevice);
+    if (rows) (void)hipMemcpy(d_b, b, (size_t)rows, hipMemcpyHostToDevice);
+    rc = sw_fill_device(c, d_a, cols, d_b, rows, scores, d_H, 4, d_P, nullptr, d_r, nullptr);
+    if (rc == SW_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) { set_err("fill kernel failed: %s", hipGetErrorString(e)); rc = SW_EDEVICE; }
+    }
+    if (rc == SW_OK) {
+        (void)hipMemcpy(result, d_r, sizeof(sw_result), hipMemcpyDeviceToHost);
+        if (result->path_len < 0) { set_err("fill kernel: hand-off wait timed out"); rc = SW_ETIMEOUT; }
+        if (H) (void)hipMemcpy(H, d_H, cells * 4, hipMemcpyDeviceToHost);
+        if (P) (void)hipMemcpy(P, d_P, cells * 4, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    return rc;
+}
+
+int sw_traceback_device(sw_ctx* c, int32_t* d_P, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path,
+                        int64_t path_cap, sw_result* d_result, void* stream_) {
+    if (!c || !d_P || !d_result || cols < 0 || rows < 0 || max_pos < 0 || max_pos >= (cols + 1) * (rows + 1)) {
+        set_err("sw_traceback_device: bad argument");
+        return SW_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipLaunchKernelGGL(swk::sw_traceback, dim3(1), dim3(64), 0, (hipStream_t)stream_, d_P, cols + 1, max_pos, d_path,
+                       d_path ? path_cap : 0, d_result);
+    HIP_TRY(hipGetLastError());
+    return SW_OK;
+}
+
+int sw_device_malloc(sw_ctx* c, size_t bytes, void** d_ptr) {
+    if (!c || !d_ptr) { set_err("sw_device_malloc: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) { set_err("sw_device_malloc: %zu bytes failed", bytes); return SW_ENOMEM; }
+    return SW_OK;
+}
+int sw_device_free(sw_ctx* c, void* d_ptr) {
+    if (!c) { set_err("sw_device_free: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return SW_OK;
+}
+int sw_memcpy_h2d(sw_ctx* c, void* d_dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!d_dst || !src))) { set_err("sw_memcpy_h2d: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (bytes) HIP_TRY(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return SW_OK;
+}
+int sw_memcpy_d2h(sw_ctx* c, void* dst, const void* d_src, size_t bytes) {
+    if (!c || (bytes && (!dst || !d_src))) { set_err("sw_memcpy_d2h: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (bytes) HIP_TRY(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return SW_OK;
+}
+int sw_synchronize(sw_ctx* c, void* stream_) {
+    if (!c) { set_err("sw_synchronize: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    return SW_OK;
+}
+
+int sw_row_checksums_device(sw_ctx* c, const void* d_X, int elem_bytes, int64_t rows1, int64_t m, uint64_t* d_cs,
+                            void* stream_) {
+    if (!c || !d_X || !d_cs || rows1 <= 0 || m <= 0 || (elem_bytes != 4 && elem_bytes != 8) || rows1 > 0x7fffffff) {
+        set_err("sw_row_checksums_device: bad argument");
+        return SW_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL((swk::sw_row_checksums<int32_t>), dim3((unsigned)rows1), dim3(256), 0, stream,
+                           (const int32_t*)d_X, m, (unsigned long long*)d_cs);
+    else
+        hipLaunchKernelGGL((swk::sw_row_checksums<int64_t>), dim3((unsigned)rows1), dim3(256), 0, stream,
+                           (const int64_t*)d_X, m, (unsigned long long*)d_cs);
+    HIP_TRY(hipGetLastError());
+    return SW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// sw_host.cpp -- host-only parts of the C-ABI (no GPU needed): the reference's input generator,
+// its wavefront indexing helpers and the host traceback.  Citations: /root/reference paths.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "../../include/swhip.h"
+
+namespace swh {
+thread_local std::string g_err;
+void set_err(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+// glibc random_r TYPE_3 (x^31 + x^3 + 1) as used by rand(): 31-word state seeded by the
+// Lehmer generator 16807 mod (2^31-1), 310 warm-up steps, outputs are state sums >> 1.
+// The reference draws from libc rand() (serial_smithW.c:338,351); restating it keeps the
+// generated sequences identical on any host libc.
+class GlibcRand {
+public:
+    explicit GlibcRand(uint32_t seed) {
+        int64_t w = seed ? seed : 1;
+        st_[0] = (uint32_t)w;
+        for (int i = 1; i < 31; ++i) {
+            w = (16807 * w) % 2147483647;      // same value as glibc's Schrage form
+            st_[i] = (uint32_t)w;
+        }
+        f_ = 3; r_ = 0;
+        for (int i = 0; i < 310; ++i) (void)next();
+    }
+    int32_t next() {
+        st_[f_] += st_[r_];
+        const uint32_t out = st_[f_] >> 1;
+        f_ = (f_ + 1 == 31) ? 0 : f_ + 1;
+        r_ = (r_ + 1 == 31) ? 0 : r_ + 1;
+        return (int32_t)out;
+    }
+private:
+    uint32_t st_[31];
+    int f_, r_;
+};
+
+inline char letter(int v) {  // serial_smithW.c:339-346
+    switch (v) { case 0: return 'A'; case 2: return 'C'; case 3: return 'G'; default: return 'T'; }
+}
+}  // namespace swh
+
+extern "C" {
+
+const char* sw_last_error(void) { return swh::g_err.c_str(); }
+const char* sw_version(void) { return "swhip 0.1 (gfx950)"; }
+
+int sw_generate(int64_t cols, int64_t rows, uint32_t seed, char* a, char* b) {
+    if (cols < 0 || rows < 0 || !a || !b) { swh::set_err("sw_generate: bad argument"); return SW_EINVAL; }
+    swh::GlibcRand rng(seed);
+    // generate() runs after m++, n++ (serial_smithW.c:91-92,129): cols+1 draws, then rows+1
+    for (int64_t i = 0; i <= cols; ++i) a[i] = swh::letter(rng.next() % 4);
+    for (int64_t i = 0; i <= rows; ++i) b[i] = swh::letter(rng.next() % 4);
+    return SW_OK;
+}
+
+int64_t sw_nelement(int64_t i, int64_t m, int64_t n) {  // omp_smithW.c:260-275
+    const int64_t lo = m < n ? m : n, hi = m < n ? n : m;
+    if (i < lo) return i;
+    if (i < hi) return lo - 1;
+    return 2 * lo - i + (hi - lo) - 2;
+}
+
+void sw_first_diag_element(int64_t i, int64_t m, int64_t n, int64_t* si, int64_t* sj) {  // omp_smithW.c:282-291
+    (void)m;
+    const bool left_edge = i < n;
+    if (si) *si = left_edge ? i : n - 1;
+    if (sj) *sj = left_edge ? 1 : i - n + 2;
+}
+
+int sw_traceback_host(int32_t* P, int64_t cols, int64_t rows, int64_t max_pos, int64_t* path,
+                      int64_t path_cap, int64_t* path_len) {  // serial_smithW.c:262-277
+    const int64_t m = cols + 1;
+    if (!P || cols < 0 || rows < 0 || max_pos < 0 || max_pos >= m * (rows + 1)) {
+        swh::set_err("sw_traceback_host: bad argument");
+        return SW_EINVAL;
+    }
+    int64_t len = 0, pos = max_pos;
+    for (int pr = P[pos]; pr > 0; pr = P[pos]) {
+        P[pos] = pr * SW_PATH;
+        if (path && len < path_cap) path[len] = pos;
+        ++len;
+        pos -= (pr == SW_DIAGONAL) ? m + 1 : (pr == SW_UP) ? m : 1;
+    }
+    if (path_len) *path_len = len;
+    return SW_OK;
+}
+
+}  // extern "C"

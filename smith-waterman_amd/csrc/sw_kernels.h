@@ -1,0 +1,33 @@
+// sw_kernels.h -- shared declarations between the HIP kernels and the C-ABI host code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/swhip.h"
+
+namespace swk {
+
+// packed arg-max key: (score << 40) | (2^40-1 - linear_index); atomicMax picks the highest
+// score and, among equals, the LOWEST linear index (the serial scan's rule, serial_smithW.c:240-242)
+constexpr unsigned long long SW_KEY_IDX_MASK = (1ull << 40) - 1;
+constexpr int64_t SW_MAX_DIM = (1 << 20) - 1; // rows/cols limit: 20-bit row tags, 40-bit indices
+
+struct FillParams {
+    int64_t cols, rows, M;     // M = cols + 1 = row stride
+    void* H;                   // HT[(rows+1)*M]
+    int32_t* P;                // int32[(rows+1)*M]
+    const int32_t* top;        // optional halo row (cols+1), NULL = zeros
+    int32_t mm, xm, ngap;      // match-2*gap, mismatch-2*gap, -gap  (G-space constants)
+    unsigned long long* edge;  // [nstrips][rows+1] {tag,value} granules
+    unsigned int tag_base;     // epoch << 20
+    unsigned long long* result_key;
+    unsigned int* abort_flag;
+    int nstrips;
+};
+
+template <typename HT, int B>
+__global__ void sw_strip_scan(const unsigned char* a, const unsigned char* b, FillParams p);
+__global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res);
+__global__ void sw_traceback(int32_t* P, int64_t M, int64_t maxPos, int64_t* path, int64_t cap, sw_result* res);
+template <typename T> __global__ void sw_row_checksums(const T* X, int64_t m, unsigned long long* cs);
+
+}  // namespace swk
