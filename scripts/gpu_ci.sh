@@ -19,6 +19,7 @@ nproc >> gpurun_out/ci.log; lscpu | grep "Model name" >> gpurun_out/ci.log
 step smoke 300 python __graft_entry__.py smoke
 step pytest_gpu 600 python -m pytest tests -m gpu -x -q
 step bench 400 python bench.py --steps 10 --warmup 2
+for w in 1 2 8; do step bench_wpb$w 200 python bench.py --steps 5 --warmup 1 --no-cpu --wpb $w; done
 export TMPDIR=/tmp
 step rocprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 5 --warmup 1 --no-cpu
 find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -8 "$f"; done

@@ -74,6 +74,10 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not built: run `make -C {_HERE}` (hipcc --offload-arch=gfx950); "
                               "there is no CPU fallback")
+        try:  # torch bundles its own HIP/HSA runtime: let it load first so the process has ONE
+            import torch  # noqa: F401  (libswhip.so then binds to the already-loaded libamdhip64)
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in ABI.items():
             fn = getattr(L, name)

@@ -60,7 +60,7 @@ void sw_destroy(sw_ctx* c) {
 int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!c || !name) { set_err("sw_set_option: bad argument"); return SW_EINVAL; }
     if (!strcmp(name, "waves_per_block")) {
-        if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8 && v != 16) { set_err("waves_per_block must be 1,2,4,8,16"); return SW_EINVAL; }
+        if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8) { set_err("waves_per_block must be 1,2,4,8"); return SW_EINVAL; }
         c->opt_waves_per_block = v ? v : 4;
         return SW_OK;
     }

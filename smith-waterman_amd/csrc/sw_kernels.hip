@@ -60,6 +60,27 @@ __device__ __forceinline__ int writelane_c(int old, int sval) {
     return old;
 }
 
+// Prefetch of the next block's edge granule that the compiler does not track (so it cannot
+// answer with s_waitcnt vmcnt(0), which would also drain this wave's H/P stores).  The landing
+// registers are the LITERAL v[126:127]: the kernel uses < 80 VGPRs, the clobber makes the kernel
+// descriptor reserve them, and no compiler value ever lives there, so the asynchronously
+// arriving data cannot corrupt anything (hipcc copies/reuses an "=v" output before the data
+// lands -- cdna_hip_programming.md 5.7 item 1).  tools/check_isa.py verifies nobody else
+// touches v126/v127.
+__device__ __forceinline__ void edge_prefetch_issue(const u64* p) {
+    asm volatile("global_load_dwordx2 v[126:127], %0, off sc1" ::"v"(p) : "memory", "v126", "v127");
+}
+// Waits until at most NYOUNGER younger vector-memory ops are outstanding, then reads the granule.
+// If the hardware ever completed a store ahead of the load the granule read here is stale, its
+// tag does not match and the caller falls back to polling: never wrong, only slower.
+template <int NYOUNGER>
+__device__ __forceinline__ u64 edge_prefetch_collect() {
+    u32 lo, hi;
+    asm volatile("s_waitcnt vmcnt(%2)\n\tv_mov_b32 %0, v126\n\tv_mov_b32 %1, v127"
+                 : "=v"(lo), "=v"(hi) : "n"(NYOUNGER) : "memory");
+    return ((u64)hi << 32) | lo;
+}
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -74,7 +95,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 //   d  = D + (a==b ? mm : xm);  z = cz + Zi;  e = max(d, U, z);  g = prefixmax(e) v carry
 //   H = g - z;  P = g==z ? NONE : d==g ? DIAGONAL : U==g ? UP : LEFT      (serial_smithW.c:204-234)
 template <typename HT, int B>
-__global__ void __launch_bounds__(256) sw_strip_scan(const unsigned char* __restrict__ seq_a,
+__global__ void __launch_bounds__(512) sw_strip_scan(const unsigned char* __restrict__ seq_a,
                                                      const unsigned char* __restrict__ seq_b, FillParams p) {
     static_assert(B == 16, "the scalar b-window and hand-counted vmcnt assume 16-row blocks");
     const int lane = threadIdx.x & 63;
@@ -132,10 +153,7 @@ __global__ void __launch_bounds__(256) sw_strip_scan(const unsigned char* __rest
             // that it cannot answer with s_waitcnt vmcnt(0) (which would also drain our stores).
             u64 gnext = 0;
             const bool have_next = !first && (i0 + B <= rows);
-            if (have_next) {
-                const u64* np = edge_addr(i0 + B);
-                asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(gnext) : "v"(np) : "memory");
-            }
+            if (have_next) edge_prefetch_issue(edge_addr(i0 + B));
             // --- this block's b characters: 16 bytes through the scalar cache (b is read-only)
             u32 bw0, bw1, bw2, bw3;
             if (full) {
@@ -170,7 +188,7 @@ __global__ void __launch_bounds__(256) sw_strip_scan(const unsigned char* __rest
                             const bool expired = (now - t0) > 300000000ull;        // 3 s
                             if (expired) __hip_atomic_store((gu32*)p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (expired || __hip_atomic_load((gu32*)p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                                asm volatile("s_waitcnt vmcnt(0)" : "+v"(gnext)::"memory");
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                                 return;
                             }
                         }
@@ -226,7 +244,7 @@ __global__ void __launch_bounds__(256) sw_strip_scan(const unsigned char* __rest
             }
             // the prefetched granules were issued before this block's 2*B row stores: wait for
             // everything older than those stores (vmcnt counts loads and stores in issue order)
-            if (have_next) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gnext) : "n"(2 * B) : "memory");
+            if (have_next) gnext = edge_prefetch_collect<2 * B>();
             if (!last && lane < nb)
                 granule_store(eout + i0 + lane, ((tag_base | (u64)(i0 + lane)) << 32) | (u64)(u32)Eout);
             gcur = gnext;

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Post-build audit of the gfx950 ISA of sw_kernels.hip (run by `make check_isa`):
+  * v126/v127 (landing registers of the hand-tracked edge prefetch) appear ONLY in the two asm
+    statements that own them;
+  * no scratch (spills) in the fill kernels."""
+import re, subprocess, sys, os, tempfile
+here = os.path.dirname(os.path.abspath(__file__))
+src = os.path.join(here, "..", "smith-waterman_amd", "csrc", "sw_kernels.hip")
+with tempfile.TemporaryDirectory() as td:
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-S", "--cuda-device-only", src,
+                    "-o", os.path.join(td, "k.s")], check=True)
+    s = open(os.path.join(td, "k.s")).read()
+bad = []
+for ln in s.splitlines():
+    t = ln.split(";")[0]
+    if re.search(r"\bv12[67]\b|v\[12[0-7]:12[67]\]|v\[126:", t):
+        if not (("global_load_dwordx2 v[126:127]" in t) or re.match(r"\s*v_mov_b32(_e32)? v\d+, v12[67]\s*$", t)):
+            bad.append(ln)
+if bad:
+    print("v126/v127 used outside the prefetch asm:\n" + "\n".join(bad)); sys.exit(1)
+for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)", s):
+    if int(m.group(1)) != 0:
+        print("scratch in use:", m.group(0)); sys.exit(1)
+n = len(re.findall(r"global_load_dwordx2 v\[126:127\]", s))
+print(f"check_isa ok: {n} prefetch sites, v126/v127 private, no scratch")
