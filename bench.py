@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--rows", type=int, default=16384)
     ap.add_argument("--h64", action="store_true", help="int64 H (BASELINE config 3 element type)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--engine", type=int, default=0, help="0 systolic (default), 1 strip_scan")
+    ap.add_argument("--ns", type=int, default=0, help="systolic: strips per workgroup")
+    ap.add_argument("--nc", type=int, default=0, help="systolic: consumer waves per strip")
+    ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--wpb", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
     args = ap.parse_args()
@@ -79,6 +83,13 @@ def main():
     torch.cuda.set_device(local)
     sw = importlib.import_module("smith-waterman_amd")
     eng = sw.Engine(local)
+    eng.set_option("engine", args.engine)
+    if args.ns:
+        eng.set_option("strips_per_group", args.ns)
+    if args.nc:
+        eng.set_option("consumers", args.nc)
+    if args.debug_flags:
+        eng.set_option("debug_flags", args.debug_flags)
     if args.wpb:
         eng.set_option("waves_per_block", args.wpb)
     if args.max_blocks:
@@ -130,7 +141,7 @@ def main():
                        "grid": eng.get_option("last_grid"), "strips": eng.get_option("last_strips")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
+                         "kernel": "sw_systolic" if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
                          "algorithmic_bytes_per_cell": bytes_per_cell},
         }
         if not args.no_cpu and world == 1:

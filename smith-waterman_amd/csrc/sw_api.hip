@@ -25,6 +25,12 @@ struct sw_ctx {
     unsigned long long* d_edge = nullptr;
     size_t edge_cap = 0;                // granules
     unsigned long long* d_key = nullptr; // [0] = arg-max key, [1] low word = abort flag
+    unsigned char* d_cb = nullptr;      // systolic engine: zero-padded copy of b (sw_pad_b)
+    size_t cb_cap = 0;
+    int64_t opt_debug = 0;
+    int64_t opt_engine = 0;             // 0 = systolic producer/consumer pipeline, 1 = strip_scan (row scan)
+    int64_t opt_strips_per_group = 2;   // systolic: producer waves (strips) per workgroup
+    int64_t opt_consumers = 2;          // systolic: consumer waves per strip
     int64_t opt_waves_per_block = 4;
     int64_t opt_max_blocks = 0;         // 0 -> 2 * CUs
     int64_t last_grid = 0, last_strips = 0;
@@ -54,6 +60,7 @@ void sw_destroy(sw_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->d_edge) (void)hipFree(c->d_edge);
     if (c->d_key) (void)hipFree(c->d_key);
+    if (c->d_cb) (void)hipFree(c->d_cb);
     delete c;
 }
 
@@ -65,6 +72,14 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
         return SW_OK;
     }
     if (!strcmp(name, "max_blocks")) { c->opt_max_blocks = v < 0 ? 0 : v; return SW_OK; }
+    if (!strcmp(name, "strips_per_group")) { c->opt_strips_per_group = v ? v : 2; return SW_OK; }
+    if (!strcmp(name, "consumers")) { c->opt_consumers = v ? v : 2; return SW_OK; }
+    if (!strcmp(name, "debug_flags")) { c->opt_debug = v; return SW_OK; }
+    if (!strcmp(name, "engine")) {
+        if (v != 0 && v != 1) { set_err("engine must be 0 (systolic) or 1 (strip_scan)"); return SW_EINVAL; }
+        c->opt_engine = v;
+        return SW_OK;
+    }
     set_err("sw_set_option: unknown option '%s'", name);
     return SW_EINVAL;
 }
@@ -73,6 +88,9 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!c || !name) return -1;
     if (!strcmp(name, "waves_per_block")) return c->opt_waves_per_block;
     if (!strcmp(name, "max_blocks")) return c->opt_max_blocks;
+    if (!strcmp(name, "engine")) return c->opt_engine;
+    if (!strcmp(name, "strips_per_group")) return c->opt_strips_per_group;
+    if (!strcmp(name, "consumers")) return c->opt_consumers;
     if (!strcmp(name, "num_cus")) return c->num_cus;
     if (!strcmp(name, "last_grid")) return c->last_grid;
     if (!strcmp(name, "last_strips")) return c->last_strips;
@@ -117,7 +135,9 @@ int sw_fill_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, in
         if (d_top && h_elem_bytes == 4) HIP_TRY(hipMemcpyAsync(d_H, d_top, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
         if (d_top && h_elem_bytes == 8) { set_err("sw_fill_device: top halo with an empty int64 band is unsupported"); return SW_EINVAL; }
     } else {
-        const int64_t S = (cols + 63) / 64;
+        const bool systolic = (c->opt_engine == 0);
+        const int64_t S = systolic ? (cols + 62) / 63 : (cols + 63) / 64;
+        if (((uintptr_t)d_b & 15) != 0) { set_err("sw_fill_device: d_b must be 16-byte aligned"); return SW_EINVAL; }
         const size_t need = (size_t)S * (size_t)(rows + 1);
         if (need > c->edge_cap) {
             HIP_TRY(hipStreamSynchronize(stream));
@@ -139,16 +159,48 @@ int sw_fill_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, in
         p.edge = c->d_edge; p.tag_base = c->epoch << 20;
         p.result_key = c->d_key; p.abort_flag = (unsigned int*)(c->d_key + 1);
         p.nstrips = (int)S;
-        const int wpb = (int)c->opt_waves_per_block;
-        const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : 2ll * c->num_cus;
-        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + wpb - 1) / wpb, maxb));
-        c->last_grid = grid; c->last_strips = S;
+        p.debug_flags = (int)c->opt_debug;
         const unsigned char* ua = (const unsigned char*)d_a;
         const unsigned char* ub = (const unsigned char*)d_b;
-        if (h_elem_bytes == 4)
-            hipLaunchKernelGGL((swk::sw_strip_scan<int32_t, 16>), dim3(grid), dim3(64 * wpb), 0, stream, ua, ub, p);
-        else
-            hipLaunchKernelGGL((swk::sw_strip_scan<int64_t, 16>), dim3(grid), dim3(64 * wpb), 0, stream, ua, ub, p);
+        if (systolic) {
+            const int NS = (int)c->opt_strips_per_group, NC = (int)c->opt_consumers;
+            const size_t ncb = (size_t)rows + 64 + 384;
+            if (ncb > c->cb_cap) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (c->d_cb) HIP_TRY(hipFree(c->d_cb));
+                c->d_cb = nullptr; c->cb_cap = 0;
+                if (hipMalloc((void**)&c->d_cb, ncb) != hipSuccess) { set_err("workspace allocation failed"); return SW_ENOMEM; }
+                c->cb_cap = ncb;
+            }
+            hipLaunchKernelGGL(swk::sw_pad_b, dim3((unsigned)((ncb + 255) / 256)), dim3(256), 0, stream, ub, rows, c->d_cb, (int64_t)ncb);
+            const int64_t ngroups = (S + NS - 1) / NS;
+            const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : (int64_t)c->num_cus;
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ngroups, maxb));
+            c->last_grid = grid; c->last_strips = S;
+            const int threads = 64 * (NS * (1 + NC) + 1);
+            const unsigned char* cbp = c->d_cb;
+            bool launched = false;
+#define SW_LAUNCH(ns, nc)                                                                                                        \
+    if (!launched && NS == ns && NC == nc) {                                                                                      \
+        launched = true;                                                                                                          \
+        if (h_elem_bytes == 4)                                                                                                    \
+            hipLaunchKernelGGL((swk::sw_systolic<int32_t, ns, nc>), dim3(grid), dim3(threads), 0, stream, ua, ub, cbp, p);       \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((swk::sw_systolic<int64_t, ns, nc>), dim3(grid), dim3(threads), 0, stream, ua, ub, cbp, p);       \
+    }
+            SW_LAUNCH(2, 2) SW_LAUNCH(2, 3) SW_LAUNCH(2, 4) SW_LAUNCH(1, 2) SW_LAUNCH(1, 4)
+#undef SW_LAUNCH
+            if (!launched) { set_err("unsupported strips_per_group/consumers combination %d/%d", NS, NC); return SW_EINVAL; }
+        } else {
+            const int wpb = (int)c->opt_waves_per_block;
+            const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : 2ll * c->num_cus;
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + wpb - 1) / wpb, maxb));
+            c->last_grid = grid; c->last_strips = S;
+            if (h_elem_bytes == 4)
+                hipLaunchKernelGGL((swk::sw_strip_scan<int32_t, 16>), dim3(grid), dim3(64 * wpb), 0, stream, ua, ub, p);
+            else
+                hipLaunchKernelGGL((swk::sw_strip_scan<int64_t, 16>), dim3(grid), dim3(64 * wpb), 0, stream, ua, ub, p);
+        }
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(swk::sw_finalize, dim3(1), dim3(64), 0, stream, c->d_key, (const unsigned int*)(c->d_key + 1), d_result);

@@ -8,6 +8,14 @@ import pytest
 from oracle_lib import GOLDEN, golden, golden_hashes
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=[0, 1], ids=["systolic", "strip_scan"])
+def engine_kind(request, engine):
+    """Every parity test runs against both fill engines behind the same C-ABI."""
+    engine.set_option("engine", request.param)
+    yield request.param
+    engine.set_option("engine", 0)
 FULL = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "*.npz")))
 
 
