@@ -164,20 +164,27 @@ int sw_fill_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, in
         const unsigned char* ub = (const unsigned char*)d_b;
         if (systolic) {
             const int NS = (int)c->opt_strips_per_group, NC = (int)c->opt_consumers;
-            const size_t ncb = (size_t)rows + 64 + 384;
+            // padded copies of b: [front zeros | b | tail]; front covers the fast producers' phi (< strips) + 63 lanes
+            const int64_t bfront = ((S + 64 + 127) / 128) * 128;
+            const size_t ncb = (size_t)rows + (size_t)bfront + 512;
             if (ncb > c->cb_cap) {
                 HIP_TRY(hipStreamSynchronize(stream));
                 if (c->d_cb) HIP_TRY(hipFree(c->d_cb));
                 c->d_cb = nullptr; c->cb_cap = 0;
-                if (hipMalloc((void**)&c->d_cb, ncb) != hipSuccess) { set_err("workspace allocation failed"); return SW_ENOMEM; }
+                if (hipMalloc((void**)&c->d_cb, ncb * 3 + 16) != hipSuccess) { set_err("workspace allocation failed"); return SW_ENOMEM; }
                 c->cb_cap = ncb;
             }
-            hipLaunchKernelGGL(swk::sw_pad_b, dim3((unsigned)((ncb + 255) / 256)), dim3(256), 0, stream, ub, rows, c->d_cb, (int64_t)ncb);
+            unsigned short* d_cb16 = (unsigned short*)(c->d_cb + ((c->cb_cap + 15) / 16) * 16);
+            hipLaunchKernelGGL(swk::sw_pad_b, dim3((unsigned)((ncb + 255) / 256)), dim3(256), 0, stream, ub, rows, bfront, c->d_cb, d_cb16, (int64_t)ncb);
+            const bool fast = (d_top == nullptr) && (sc->mismatch <= 0) && !(c->opt_debug & 4);
+            p.phi_base = fast ? (int)S - 1 : -1;
+            p.bfront = (int)bfront;
+            p.bpad16 = d_cb16;
             const int64_t ngroups = (S + NS - 1) / NS;
             const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : (int64_t)c->num_cus;
             const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ngroups, maxb));
             c->last_grid = grid; c->last_strips = S;
-            const int threads = 64 * (NS * (1 + NC) + 1);
+            const int threads = 64 * (NS * (1 + NC) + 2);
             const unsigned char* cbp = c->d_cb;
             bool launched = false;
 #define SW_LAUNCH(ns, nc)                                                                                                        \

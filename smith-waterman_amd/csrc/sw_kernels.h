@@ -21,6 +21,9 @@ struct FillParams {
     unsigned int tag_base;     // epoch << 20
     unsigned long long* result_key;
     unsigned int* abort_flag;
+    int phi_base;              // systolic: >= 0 -> fast producers, phi = phi_base - s; < 0 -> generic
+    int bfront;                // systolic: index of b[0] inside bpad / bpad16
+    const unsigned short* bpad16;
     int debug_flags;           // bit0: drop the H/P stores (timing experiments only)
     int nstrips;               // strip_scan: ceil(cols/64); systolic: ceil(cols/63)
 };
@@ -29,7 +32,7 @@ template <typename HT, int B>
 __global__ void sw_strip_scan(const unsigned char* a, const unsigned char* b, FillParams p);
 template <typename HT, int NS, int NC>
 __global__ void sw_systolic(const unsigned char* a, const unsigned char* b, const unsigned char* bpad, FillParams p);
-__global__ void sw_pad_b(const unsigned char* b, int64_t rows, unsigned char* bpad, int64_t n);
+__global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, unsigned char* bpad, unsigned short* bpad16, int64_t n);
 __global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res);
 __global__ void sw_traceback(int32_t* P, int64_t M, int64_t maxPos, int64_t* path, int64_t cap, sw_result* res);
 template <typename T> __global__ void sw_row_checksums(const T* X, int64_t m, unsigned long long* cs);

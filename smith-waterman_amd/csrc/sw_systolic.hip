@@ -1,31 +1,37 @@
 // sw_systolic.hip -- the wavefront fill as a systolic producer/consumer pipeline (gfx950).
 //
-// Measured on MI355X (profiles/r01_ubench_issue_latency.log): one wave issues INDEPENDENT VALU
-// ops every ~1.15 clk but a DEPENDENT op only every ~4.5 clk (~12.5 clk when the dependence goes
-// through a DPP lane shift).  The DP recurrence is one long dependence chain, so the fill is
-// latency-bound and the design goal is: as few dependent ops per anti-diagonal step as possible,
-// everything else issued in their shadow or moved to other waves.
+// Measured on MI355X (profiles/r01_ubench_*.log): for a lone wave every instruction of the
+// recurrence costs ~4.3 clk whatever its dependences (the bare 3-op recurrence runs at 14 clk per
+// step, a ds_write_b32 adds 16 clk, a ds_write_b128 per four steps ~1 clk per step), and a
+// cross-workgroup hand-off costs ~0.4 us one way.  So a strip's speed is set by the NUMBER of
+// instructions its producer wave issues per anti-diagonal step: the producer runs the recurrence
+// and nothing else (6 instructions per step + 2 LDS ops per 4 steps), everything else (H/P
+// derivation, arg-max, HBM stores, inter-workgroup traffic) lives in other waves.
 //
 // G-space (see sw_kernels.hip):  G = H - gap*(row+col);  Z = -gap*(row+col) is the H==0 floor and
 // is the SAME for all cells of one anti-diagonal.
 //
 // Strip s = matrix columns 63*s .. 63*s+63.  Lane l owns column 63*s+l; lane 0 is the strip's
-// left halo column (= lane 63 of strip s-1), so every lane finds its left/diagonal neighbour
-// one lane down.  At step t lane l works on row r = t - l, i.e. one wave sweeps an
-// anti-diagonal down the strip:
-//     m = max(G1[l-1], G1[l])          v_max_i32_dpp wave_shr:1     (G1 = values of step t-1)
-//     d = G2[l-1] + s'                 v_add_u32_dpp wave_shr:1     (G2 = step t-2; off the chain)
-//     g = max3(d, m, Z_t)              v_max3_i32                    -> 2 dependent ops per step
-// (signed: G >= 0 always, but d can dip below 0 when mismatch - 2*gap < 0)
-// Lane 0 is never written by the two DPP ops (no source lane), so m[0] stays 0 and d[0] is
-// preloaded with the halo value of row t: g[0] = halo(t) falls out of the same max3.
+// left halo column (= lane 63 of strip s-1), so every lane finds its left/diagonal neighbour one
+// lane down.  At local step u lane l works on row r = u - phi - l (phi = (-s) mod 4, see below):
+//     m = max(G1[l-1], G1[l])          v_max_i32_dpp wave_shr:1     (G1 = values of step u-1)
+//     d = G2[l-1] + s'                 v_add_u32_dpp wave_shr:1     (G2 = step u-2)
+//     g = max3(d, m, Z)                v_max3_i32
+// Lane 0 is never written by the two DPP ops (no source lane): m[0] stays "minus infinity" and
+// d[0] was loaded with the halo value of that step (a broadcast ds_read_b128 fetches four steps
+// of halo straight into the four d registers), so g[0] = halo falls out of the same max3.
 //
-// Roles inside one workgroup (NS strips): NS producer waves run the recurrence only and write
-// each step's 64 values to an LDS ring (diagonal-major); NS*NC consumer waves read the ring
-// row-major (skewed addresses, conflict-free), derive H and P and write them to HBM with one
-// coalesced 252-byte store per matrix row; one helper wave moves the strip-edge column between
-// workgroups through HBM/L2 as {tag,value} granules.  All intra-workgroup hand-offs are LDS
-// counters written in order behind the data they cover.
+// LDS ring of a strip, lane-major: lane l, step u at  l*SY_LSTR + ((u-1) mod R)*4  (SY_LSTR =
+// 4R+16 keeps b128 accesses of 8 neighbouring lanes on distinct banks).  A producer writes four
+// steps with one ds_write_b128; a consumer reads matrix row r of lane l at step r+l+phi, i.e. along
+// the skew (conflict-free); the right-hand strip reads lane 63's four values of steps u+63...
+// with one ds_read_b128.  phi shifts each strip's step numbering so that this read is 16-byte
+// aligned: (63 + phi[s-1] - phi[s]) mod 4 == 0.
+//
+// Roles in one workgroup (NS strips): NS producer waves, NS*NC consumer waves (derive H and P
+// from the ring, row-major coalesced HBM stores, arg-max), an importer and an exporter wave (move the
+// edge column between workgroups through HBM/L2 as {tag,value} granules).  Hand-offs inside the workgroup are
+// LDS counters written in order behind the data they cover.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -38,29 +44,27 @@ typedef unsigned int u32;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) u32 gu32;
 
-#ifndef SW_RING
-#define SW_RING 256
-#endif
-constexpr int SY_R = SW_RING;  // ring slots (steps) per strip: 256 B each
-constexpr int SY_U = 16;     // steps per producer block / rows per consumer block
-constexpr int SY_RH = 256;   // imported-halo ring entries (rows)
-constexpr int SY_W = 63;     // real columns per strip
+constexpr int SY_R = 256;               // ring entries (steps) per lane
+constexpr int SY_LSTR = SY_R * 4 + 16;  // byte stride between lanes in a ring
+constexpr int SY_U = 16;                // steps per producer block / rows per consumer block
+constexpr int SY_RH = 1024;             // imported-halo ring entries (steps)
+constexpr int SY_W = 63;                // real columns per strip
 constexpr u32 SY_OOB = 0xFFFFFF00u;
-constexpr int SY_ASENT = 0x200;  // never-matching character for lanes without a column
+constexpr int SY_ASENT = 0x200;         // never-matching character for lanes without a column
 
-template <int NS, int NC>
+template <int NS>
 struct SysLds {
-    u32 ring[NS][SY_R][64];
-    u32 halo[SY_RH];
-    __attribute__((aligned(16))) int cons_blk[NS][4];  // latest completed 16-row block per consumer (-1: none; unused: INT_MAX)
-    int prod_t[NS];        // completed steps of each producer
-    int halo_ready;        // imported halo rows: every row < halo_ready is in halo[]
-    int exp_done;          // exported edge rows: every row <= exp_done is in HBM
-    int never;             // INT_MAX: "neighbour" of a strip nobody waits behind
+    __attribute__((aligned(16))) unsigned char ring[NS][64 * SY_LSTR];
+    __attribute__((aligned(16))) u32 halo[SY_RH];      // edge column imported from the previous workgroup
+    __attribute__((aligned(16))) int cons_blk[NS][4];  // latest completed 16-row block per consumer (-1 none; unused INT_MAX)
+    int prod_u[NS];   // completed local steps of each producer
+    int halo_ready;   // imported halo: every local step (strip s0's numbering) < halo_ready is in halo[]
+    int exp_done;     // exported edge rows: every row <= exp_done is in HBM
+    int never;        // INT_MAX
 };
 
-// counters are wave-uniform by construction; readfirstlane makes that provable, so every poll
-// loop is a scalar branch and the SGPR state of the producer's asm stays in SGPRs
+// counters are wave-uniform by construction; readfirstlane makes that provable, so every poll loop
+// is a scalar branch
 __device__ __forceinline__ int lds_load(const int* p) {
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
@@ -91,90 +95,361 @@ __device__ __forceinline__ void sfor(F&& f) {
     }
 }
 
-// One anti-diagonal step of a producer, hand-scheduled (hipcc pads no hazards inside asm):
-//  * v_cmp(sdwa) -> v_cndmask via VCC and v_readlane -> v_writelane via an SGPR: 2 instructions apart
-//    (gfx940+: a VALU write of an SGPR/VCC needs 2 wait states before a VALU read)
-//  * a DPP source VGPR must have been written >= 2 instructions earlier: G1 (= previous step's g)
-//    is followed by v_add/ds_write/v_cmp/v_readlane, G2 is two steps old.
-// C holds 4 of this lane's next row characters; byte K&3 is the character of the row this lane
-// works on at this step (each lane walks b[] at its own offset, so nothing has to be shifted).
-#define SW_PRODUCER_STEP_ASM(BYTE)                                                                  \
-    asm volatile(                                                                                   \
-        "v_cmp_eq_u32_sdwa vcc, %[a], %[C] src0_sel:DWORD src1_sel:" BYTE "\n\t"                    \
-        "v_readlane_b32 %[sh], %[Hv], %[k]\n\t"                                                     \
-        "v_max_i32_dpp %[m], %[G1], %[G1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                \
-        "v_cndmask_b32 %[sp], %[xm], %[mm], vcc\n\t"                                                \
-        "v_writelane_b32 %[d], %[sh], 0\n\t"                                                        \
-        "v_add_u32_dpp %[d], %[G2], %[sp] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                \
-        "v_max3_i32 %[g], %[d], %[m], %[Z]\n\t"                                                     \
-        "v_add_u32 %[Z], %[Z], %[ngap]\n\t"                                                         \
-        "ds_write_b32 %[waddr], %[g] offset:%[off]\n\t"                                             \
-        : [sh] "=&s"(sh), [m] "+v"(m), [d] "+v"(d), [g] "=&v"(g), [Z] "+v"(Z), [sp] "=&v"(sp)       \
-        : [Hv] "v"(Hv), [G1] "v"(G1), [G2] "v"(G2), [C] "v"(C), [a] "v"(a_l), [ngap] "v"(ngap_v),   \
-          [waddr] "v"(waddr), [xm] "v"(xm_v), [mm] "v"(mm_v), [k] "n"(K & 15), [off] "n"((K & 15) * 256) \
-        : "vcc", "memory")
+// per-strip shift of the step numbering.  generic producer: (-s) mod 4 (halo read 16-byte aligned);
+// fast producer: phi_base - s (halo always at left step u+64, a 64-step chunk never wraps in the ring)
+__device__ __forceinline__ int phi_of(int s, int phi_base) { return phi_base >= 0 ? phi_base - s : (4 - (s & 3)) & 3; }
 
-template <int K>
-__device__ __forceinline__ u32 producer_step(u32 G1, u32 G2, u32& m, u32& d, u32 Hv, u32 a_l, u32 C, u32& Z,
-                                             u32 ngap_v, u32 xm_v, u32 mm_v, u32 waddr) {
-    u32 g, sp;
-    int sh;
-    if constexpr ((K & 3) == 0) SW_PRODUCER_STEP_ASM("BYTE_0");
-    if constexpr ((K & 3) == 1) SW_PRODUCER_STEP_ASM("BYTE_1");
-    if constexpr ((K & 3) == 2) SW_PRODUCER_STEP_ASM("BYTE_2");
-    if constexpr ((K & 3) == 3) SW_PRODUCER_STEP_ASM("BYTE_3");
-    return g;
+// =================================================================================================
+// Producer inner loop: ONE asm statement per 16-step block.  Literal registers are used only as
+// temporaries inside the statement (hipcc allocates its own values anywhere, also in v100+, so no
+// state may sit in a literal register between statements; tools/check_isa.py audits this):
+//   v[100:107] the last 8 step results (ds_write_b128 needs them contiguous)
+//   v[116:119], v[108:111]  d registers of groups 1/3 and 2 (lane 0 = halo, landed by ds_read_b128)
+//   v112 m   v113 s'   v120 counter snapshot
+// Crossing statements as ordinary operands: G1, G2 (last two results), Z (floor), h0..h3 (halo of
+// the NEXT block's first group, loaded and waited for inside this statement), cnt (left progress).
+// Hazards are hand-scheduled (hipcc pads nothing inside asm): v_cmp -> v_cndmask through VCC two
+// instructions apart; a DPP source written at least two instructions earlier.
+// =================================================================================================
+#define SW_STEP(GN, G1, G2, D, C, BYTE)                                                       \
+    "v_cmp_eq_u32_sdwa vcc, %[a], %[" C "] src0_sel:DWORD src1_sel:" BYTE "\n\t"             \
+    "v_max_i32_dpp v112, " G1 ", " G1 " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"           \
+    "v_add_u32 %[Z], %[Z], %[ngap]\n\t"                                                      \
+    "v_cndmask_b32 v113, %[xm], %[mm], vcc\n\t"                                              \
+    "v_add_u32_dpp " D ", " G2 ", v113 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"            \
+    "v_max3_i32 " GN ", " D ", v112, %[Z]\n\t"
+// prologue variant: the lane whose row is 0 at this step takes the halo-row value G0
+#define SW_STEP_PRO(GN, G1, G2, D, C, BYTE, KK)                                              \
+    SW_STEP(GN, G1, G2, D, C, BYTE)                                                          \
+    "v_cmp_eq_u32 vcc, %[kb]+" KK ", %[injv]\n\t"                                            \
+    "s_nop 1\n\t"                                                                            \
+    "v_cndmask_b32 " GN ", " GN ", %[g0v], vcc\n\t"                                          \
+    "s_nop 0\n\t"
+#define SW_S(GN, G1, G2, D, C, BYTE, KK) SW_STEP(GN, G1, G2, D, C, BYTE)
+#define SW_SP(GN, G1, G2, D, C, BYTE, KK) SW_STEP_PRO(GN, G1, G2, D, C, BYTE, KK)
+#define SW_GROUP_EVEN(S, C, D0, D1, D2, D3, K0, K1, K2, K3)                                   \
+    S("v100", "v107", "v106", D0, C, "BYTE_0", K0) S("v101", "v100", "v107", D1, C, "BYTE_1", K1) \
+    S("v102", "v101", "v100", D2, C, "BYTE_2", K2) S("v103", "v102", "v101", D3, C, "BYTE_3", K3)
+#define SW_GROUP_ODD(S, C, D0, D1, D2, D3, K0, K1, K2, K3)                                    \
+    S("v104", "v103", "v102", D0, C, "BYTE_0", K0) S("v105", "v104", "v103", D1, C, "BYTE_1", K1) \
+    S("v106", "v105", "v104", D2, C, "BYTE_2", K2) S("v107", "v106", "v105", D3, C, "BYTE_3", K3)
+
+#define SW_LITERALS "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
+                    "v112", "v113", "v116", "v117", "v118", "v119", "v120"
+
+// LDS traffic of a block, in issue order (lgkmcnt counts are exact because the whole block is one
+// statement): R1=halo(g1) | W0 | R2=halo(g2) Rc=counter | W1 | R3=halo(g3) Rn0..3=next block's halo |
+// W2 | W3 | wait for everything but the two youngest writes.
+#define SW_BLOCK(S, KB)                                                                                           \
+    asm volatile(                                                                                                 \
+        "v_mov_b32 v107, %[G1]\n\t"                                                                               \
+        "v_mov_b32 v106, %[G2]\n\t"                                                                               \
+        "v_mov_b32 v112, 0xe0000000\n\t"                                                                          \
+        "ds_read_b128 v[116:119], %[ra1]\n\t"                                                                     \
+        SW_GROUP_EVEN(S, "c0", "%[h0]", "%[h1]", "%[h2]", "%[h3]", "1", "2", "3", "4")                             \
+        "ds_write_b128 %[waddr], v[100:103] offset:%[o0]\n\t"                                                     \
+        "s_waitcnt lgkmcnt(1)\n\t"                                                                                \
+        "ds_read_b128 v[108:111], %[ra2]\n\t"                                                                     \
+        "ds_read_b32 v120, %[cnt_addr]\n\t"                                                                       \
+        SW_GROUP_ODD(S, "c1", "v116", "v117", "v118", "v119", "5", "6", "7", "8")                                  \
+        "ds_write_b128 %[waddr], v[104:107] offset:%[o1]\n\t"                                                     \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                                                \
+        "ds_read_b128 v[116:119], %[ra3]\n\t"                                                                     \
+        "ds_read_b32 %[h0], %[ran]\n\t"                                                                           \
+        "ds_read_b32 %[h1], %[ran] offset:4\n\t"                                                                  \
+        "ds_read_b32 %[h2], %[ran] offset:8\n\t"                                                                  \
+        "ds_read_b32 %[h3], %[ran] offset:12\n\t"                                                                 \
+        SW_GROUP_EVEN(S, "c2", "v108", "v109", "v110", "v111", "9", "10", "11", "12")                              \
+        "ds_write_b128 %[waddr], v[100:103] offset:%[o2]\n\t"                                                     \
+        "s_waitcnt lgkmcnt(5)\n\t"                                                                                \
+        SW_GROUP_ODD(S, "c3", "v116", "v117", "v118", "v119", "13", "14", "15", "16")                              \
+        "ds_write_b128 %[waddr], v[104:107] offset:%[o3]\n\t"                                                     \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                                                \
+        "v_readfirstlane_b32 %[cnt], v120\n\t"                                                                    \
+        "v_mov_b32 %[G1], v107\n\t"                                                                               \
+        "v_mov_b32 %[G2], v106\n\t"                                                                               \
+        : [G1] "+v"(G1), [G2] "+v"(G2), [Z] "+v"(Z), [h0] "+v"(h0), [h1] "+v"(h1), [h2] "+v"(h2), [h3] "+v"(h3),   \
+          [cnt] "=s"(cnt)                                                                                         \
+        : [a] "v"(a_l), [c0] "v"(C.x), [c1] "v"(C.y), [c2] "v"(C.z), [c3] "v"(C.w), [xm] "v"(xm_v), [mm] "v"(mm_v), \
+          [ngap] "v"(ngap_v), [injv] "v"(injv), [g0v] "v"(G0v), [waddr] "v"(waddr), [ra1] "v"(ra1), [ra2] "v"(ra2),  \
+          [ra3] "v"(ra3), [ran] "v"(ran), [cnt_addr] "v"(cnt_addr), [kb] "n"(KB), [o0] "n"(KB * 4),                  \
+          [o1] "n"(KB * 4 + 16), [o2] "n"(KB * 4 + 32), [o3] "n"(KB * 4 + 48)                                       \
+        : "vcc", "memory", SW_LITERALS)
+
+
+// =================================================================================================
+// Fast producer: the WHOLE strip loop is one asm statement (hipcc's code between block statements
+// -- structurizer branches, SGPR spills through v_readlane, full lgkmcnt drains -- cost as much as
+// the steps themselves).  Used when the matrix has no halo row (top == NULL) and mismatch <= 0:
+// then the cells above row 1 need no injection, because with never-matching characters (16-bit
+// character stream, 0x100 outside the sequence) the recurrence reproduces the H == 0 floor there
+// by itself.  phi = phi_base - s here, so every strip reads its halo at left step u+64 and a
+// 64-step chunk never wraps inside the 256-entry ring: all LDS addresses are base + immediate.
+//
+// literal registers (temporaries of this one statement):
+//   v[64:95]  four 8-dword character buffers (16 steps each, 16-bit characters), loaded 3 blocks ahead
+//   v96 per-lane character byte offset     v56..v59 LDS addresses of the counters
+//   v[100:107] last 8 step results   v[108:111], v[116:119], v[122:125] d registers (lane 0 = halo)
+//   v112 m  v113 s'  v114 floor  v120/v121 scratch  v126 ring write address  v127/v115 halo read bases
+//   s84 have_halo  s85..s87 scratch  s88 u0  s89 spin count  s90/s91 chunk byte offset in my ring / the halo
+//   source ring  s[92:93] char base
+// =================================================================================================
+#define SF_STEP(GN, G1, G2, D, CREG, WSEL)                                                    \
+    "v_cmp_eq_u32_sdwa vcc, %[a], " CREG " src0_sel:DWORD src1_sel:" WSEL "\n\t"             \
+    "v_max_i32_dpp v112, " G1 ", " G1 " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"           \
+    "v_add_u32 v114, v114, %[ngap]\n\t"                                                      \
+    "v_cndmask_b32 v113, %[xm], %[mm], vcc\n\t"                                              \
+    "v_add_u32_dpp " D ", " G2 ", v113 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"            \
+    "v_max3_i32 " GN ", " D ", v112, v114\n\t"
+#define SF_EVEN(CA, CB, D0, D1, D2, D3)                                                      \
+    SF_STEP("v100", "v107", "v106", D0, CA, "WORD_0") SF_STEP("v101", "v100", "v107", D1, CA, "WORD_1") \
+    SF_STEP("v102", "v101", "v100", D2, CB, "WORD_0") SF_STEP("v103", "v102", "v101", D3, CB, "WORD_1")
+#define SF_ODD(CA, CB, D0, D1, D2, D3)                                                       \
+    SF_STEP("v104", "v103", "v102", D0, CA, "WORD_0") SF_STEP("v105", "v104", "v103", D1, CA, "WORD_1") \
+    SF_STEP("v106", "v105", "v104", D2, CB, "WORD_0") SF_STEP("v107", "v106", "v105", D3, CB, "WORD_1")
+// one 16-step block.  KB: first step's index in the chunk; C0..C7: this block's character dwords;
+// NB: the buffer (tuples) that receives the characters of the block three ahead; PF: their byte offset;
+// RAN: where the next block's first four halo values are read from
+#define SF_BLOCK(KB, O0, O1, O2, O3, R1, R2, R3, C0, C1, C2, C3, C4, C5, C6, C7, NBA, NBB, PF0, PF1, RAN) \
+    "s_cmp_eq_u32 s84, 0\n\t"                                                                \
+    "s_cbranch_scc1 Lslow" #KB "_%=\n"                                                       \
+    "Lgo" #KB "_%=:\n\t"                                                                     \
+    "s_waitcnt vmcnt(4)\n\t"                                                                 \
+    "global_load_dwordx4 " NBA ", v96, s[92:93] offset:" PF0 "\n\t"                          \
+    "global_load_dwordx4 " NBB ", v96, s[92:93] offset:" PF1 "\n\t"                          \
+    "ds_read_b128 v[116:119], v127 offset:" R1 "\n\t"                                        \
+    SF_EVEN(C0, C1, "v122", "v123", "v124", "v125")                                          \
+    "ds_write_b128 v126, v[100:103] offset:" O0 "\n\t"                                       \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                               \
+    "ds_read_b128 v[108:111], v127 offset:" R2 "\n\t"                                        \
+    "ds_read_b32 v120, v56\n\t"                                                              \
+    SF_ODD(C2, C3, "v116", "v117", "v118", "v119")                                           \
+    "ds_write_b128 v126, v[104:107] offset:" O1 "\n\t"                                       \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                               \
+    "ds_read_b128 v[116:119], v127 offset:" R3 "\n\t"                                        \
+    "ds_read_b128 v[122:125], " RAN "\n\t"                                                   \
+    SF_EVEN(C4, C5, "v108", "v109", "v110", "v111")                                          \
+    "ds_write_b128 v126, v[100:103] offset:" O2 "\n\t"                                       \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                               \
+    SF_ODD(C6, C7, "v116", "v117", "v118", "v119")                                           \
+    "ds_write_b128 v126, v[104:107] offset:" O3 "\n\t"                                       \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                               \
+    "v_readfirstlane_b32 s85, v120\n\t"                                                      \
+    "s_add_i32 s86, s88, %[k1]\n\t"                                                          \
+    "s_min_i32 s86, s86, %[k2]\n\t"                                                          \
+    "s_cmp_ge_i32 s85, s86\n\t"                                                              \
+    "s_cselect_b32 s84, 1, 0\n\t"                                                            \
+    "s_add_i32 s87, s88, 15\n\t"                                                             \
+    "v_mov_b32 v121, s87\n\t"                                                                \
+    "ds_write_b32 v59, v121\n\t"                                                             \
+    "s_add_i32 s88, s88, 16\n\t"                                                             \
+    "s_cmp_gt_i32 s88, %[ut]\n\t"                                                            \
+    "s_cbranch_scc1 Lexit_%=\n\t"
+// out-of-line: wait until the left neighbour has produced this block's halo, then fetch its first group
+#define SF_SLOW(KB, R0)                                                                       \
+    "Lslow" #KB "_%=:\n\t"                                                                   \
+    "s_mov_b32 s89, 0\n"                                                                     \
+    "Lpoll" #KB "_%=:\n\t"                                                                   \
+    "ds_read_b32 v120, v56\n\t"                                                              \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+    "v_readfirstlane_b32 s85, v120\n\t"                                                      \
+    "s_add_i32 s86, s88, %[k1]\n\t"                                                          \
+    "s_add_i32 s86, s86, -16\n\t"                                                            \
+    "s_min_i32 s86, s86, %[k2]\n\t"                                                          \
+    "s_cmp_ge_i32 s85, s86\n\t"                                                              \
+    "s_cbranch_scc1 Lrd" #KB "_%=\n\t"                                                       \
+    "s_sleep 1\n\t"                                                                          \
+    "s_add_i32 s89, s89, 1\n\t"                                                              \
+    "s_cmp_lt_u32 s89, 0x1000000\n\t"                                                        \
+    "s_cbranch_scc1 Lpoll" #KB "_%=\n\t"                                                     \
+    "s_mov_b32 %[status], 1\n\t"                                                             \
+    "s_branch Lexit_%=\n"                                                                    \
+    "Lrd" #KB "_%=:\n\t"                                                                     \
+    "ds_read_b128 v[122:125], v127 offset:" R0 "\n\t"                                        \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+    "s_branch Lgo" #KB "_%=\n"
+
+__device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ngap_v, u32 wbase, u32 voff, u32 z0,
+                                             const unsigned short* cbase, u32 hbase, int hoff4, u32 cnt_addr,
+                                             u32 cons_addr, u32 right_addr, u32 prog_addr, int UT, int k1, int k2, int kc, int kr, int hmask) {
+    int status;
+    asm volatile(
+        "s_setprio 3\n\t"                          /* producers own the critical path: win VALU arbitration on their SIMD */
+        "s_mov_b32 %[status], 0\n\t"
+        "s_mov_b32 s84, 0\n\t"
+        "s_mov_b32 s88, 1\n\t"
+        "s_mov_b32 s90, 0\n\t"
+        "s_and_b32 s91, %[hoff4], %[hmask]\n\t"   /* byte offset of this chunk's halo inside the halo source ring */
+        "s_mov_b64 s[92:93], %[cbase]\n\t"
+        "v_mov_b32 v96, %[voff]\n\t"
+        "v_mov_b32 v56, %[cntaddr]\n\t"
+        "v_mov_b32 v57, %[consaddr]\n\t"
+        "v_mov_b32 v58, %[rightaddr]\n\t"
+        "v_mov_b32 v59, %[progaddr]\n\t"
+        "v_mov_b32 v107, %[z0]\n\t"               /* step 0: every lane's cell is above the matrix: the H == 0 floor */
+        "v_sub_u32 v106, %[z0], %[ngap]\n\t"      /* step -1 */
+        "v_mov_b32 v112, 0xe0000000\n\t"
+        "v_mov_b32 v114, %[z0]\n\t"
+        "s_nop 4\n\t"
+        "global_load_dwordx4 v[64:67], v96, s[92:93] offset:0\n\t"
+        "global_load_dwordx4 v[68:71], v96, s[92:93] offset:16\n\t"
+        "global_load_dwordx4 v[72:75], v96, s[92:93] offset:32\n\t"
+        "global_load_dwordx4 v[76:79], v96, s[92:93] offset:48\n\t"
+        "global_load_dwordx4 v[80:83], v96, s[92:93] offset:64\n\t"
+        "global_load_dwordx4 v[84:87], v96, s[92:93] offset:80\n"
+        "Lchunk_%=:\n\t"
+        // ---- ring back-pressure, once per 64 steps: my consumers and my right-hand reader
+        "s_mov_b32 s89, 0\n"
+        "Lbp_%=:\n\t"
+        "ds_read_b128 v[116:119], v57\n\t"
+        "ds_read_b32 v120, v58\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_min_i32 v116, v116, v117\n\t"
+        "v_min3_i32 v116, v116, v118, v119\n\t"
+        "s_nop 0\n\t"
+        "v_readfirstlane_b32 s85, v116\n\t"
+        "v_readfirstlane_b32 s86, v120\n\t"
+        "s_lshl_b32 s85, s85, 4\n\t"
+        "s_add_i32 s85, s85, 16\n\t"
+        "s_add_i32 s87, s88, %[kc]\n\t"
+        "s_cmp_ge_i32 s85, s87\n\t"
+        "s_cbranch_scc0 Lbpw_%=\n\t"
+        "s_add_i32 s87, s88, %[kr]\n\t"
+        "s_cmp_ge_i32 s86, s87\n\t"
+        "s_cbranch_scc1 Lbpok_%=\n"
+        "Lbpw_%=:\n\t"
+        "s_sleep 1\n\t"
+        "s_add_i32 s89, s89, 1\n\t"
+        "s_cmp_lt_u32 s89, 0x1000000\n\t"
+        "s_cbranch_scc1 Lbp_%=\n\t"
+        "s_mov_b32 %[status], 2\n\t"
+        "s_branch Lexit_%=\n"
+        "Lbpok_%=:\n\t"
+        // ---- this chunk's LDS addresses: ring write base, halo read base, next chunk's halo read base
+        "v_add_u32 v126, s90, %[wbase]\n\t"
+        "v_mov_b32 v127, %[hbase]\n\t"
+        "v_add_u32 v127, s91, v127\n\t"
+        "s_add_i32 s91, s91, 256\n\t"
+        "s_and_b32 s91, s91, %[hmask]\n\t"
+        "v_mov_b32 v115, %[hbase]\n\t"
+        "v_add_u32 v115, s91, v115\n\t"
+        SF_BLOCK(0, "0", "16", "32", "48", "16", "32", "48", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
+                 "v[88:91]", "v[92:95]", "96", "112", "v127 offset:64")
+        SF_BLOCK(16, "64", "80", "96", "112", "80", "96", "112", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
+                 "v[64:67]", "v[68:71]", "128", "144", "v127 offset:128")
+        SF_BLOCK(32, "128", "144", "160", "176", "144", "160", "176", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",
+                 "v[72:75]", "v[76:79]", "160", "176", "v127 offset:192")
+        SF_BLOCK(48, "192", "208", "224", "240", "208", "224", "240", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
+                 "v[80:83]", "v[84:87]", "192", "208", "v115")
+        "s_add_i32 s90, s90, 256\n\t"
+        "s_and_b32 s90, s90, 1023\n\t"
+        "s_add_u32 s92, s92, 128\n\t"
+        "s_addc_u32 s93, s93, 0\n\t"
+        "s_branch Lchunk_%=\n"
+        SF_SLOW(0, "0") SF_SLOW(16, "64") SF_SLOW(32, "128") SF_SLOW(48, "192")
+        "Lexit_%=:\n\t"
+        "s_setprio 0\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        : [status] "=&s"(status)
+        : [a] "v"(a_l), [xm] "v"(xm_v), [mm] "v"(mm_v), [ngap] "v"(ngap_v), [wbase] "v"(wbase), [voff] "v"(voff), [z0] "v"(z0),
+          [cbase] "s"(cbase), [hbase] "s"(hbase), [hoff4] "s"(hoff4), [cntaddr] "s"(cnt_addr), [consaddr] "s"(cons_addr),
+          [rightaddr] "s"(right_addr), [progaddr] "s"(prog_addr), [ut] "s"(UT), [k1] "s"(k1), [k2] "s"(k2), [kc] "s"(kc), [kr] "s"(kr), [hmask] "s"(hmask)
+        : "vcc", "scc", "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
+          "v56", "v57", "v58", "v59", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+          "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91",
+          "v92", "v93", "v94", "v95", "v96", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
+          "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+          "v124", "v125", "v126", "v127");
+    return status;
 }
 
-// ---- producer-side counter snapshots ------------------------------------------------------------
-// Polling an LDS counter costs a ~64-clk round trip; done at every block boundary it would cost
-// more than the 16 steps themselves.  So the producer issues its reads (left/right neighbour
-// progress, its consumers' progress, next block's halo values) in the MIDDLE of a block and picks
-// the results up at the next block boundary with a counted s_waitcnt: exactly 9 younger LDS ops
-// follow the reads (8 ring writes + the progress store; lgkmcnt is 4 bits on gfx9).  The landing
-// registers are literal v120..v126, which no compiler value ever uses (tools/check_isa.py), so the
-// asynchronously landing data cannot hit a live register (cdna_hip_programming.md 5.7 item 1).
-__device__ __forceinline__ void snap_issue(u32 left_addr, u32 cons_addr, u32 right_addr) {
-    asm volatile("ds_read_b32 v124, %0\n\tds_read_b128 v[120:123], %1\n\tds_read_b32 v125, %2"
-                 :: "v"(left_addr), "v"(cons_addr), "v"(right_addr)
-                 : "memory", "v120", "v121", "v122", "v123", "v124", "v125");
-}
-__device__ __forceinline__ void halo_issue(u32 addr) {
-    asm volatile("ds_read_b32 v126, %0" :: "v"(addr) : "memory", "v126");
-}
-struct Snap { int left, c0, c1, c2, c3, right; u32 hv; };
-__device__ __forceinline__ Snap snap_collect() {
-    Snap r;
-    asm volatile("s_waitcnt lgkmcnt(9)\n\t"
-                 "v_readfirstlane_b32 %0, v124\n\t"
-                 "v_readfirstlane_b32 %1, v120\n\t"
-                 "v_readfirstlane_b32 %2, v121\n\t"
-                 "v_readfirstlane_b32 %3, v122\n\t"
-                 "v_readfirstlane_b32 %4, v123\n\t"
-                 "v_readfirstlane_b32 %5, v125\n\t"
-                 "v_mov_b32 %6, v126"
-                 : "=s"(r.left), "=s"(r.c0), "=s"(r.c1), "=s"(r.c2), "=s"(r.c3), "=s"(r.right), "=v"(r.hv)
-                 :: "memory");
-    return r;
+
+// =================================================================================================
+// Consumer: four matrix rows per asm statement, hand-scheduled (literal registers are temporaries
+// of the statement only).  Per row: s' (cmp+cndmask), diagonal candidate (DPP-fused add), z, H,
+// three compares + three selects for P (serial_smithW.c:204-234: first of DIAGONAL, UP, LEFT that
+// attains a positive maximum) and one v_max for the arg-max.  Compares are batched so that every
+// VALU-written mask is read at least two instructions later (gfx940 hazard), i.e. no s_nop at all.
+//   v[100:103] s'   v[104:107] diagonal candidates   v[116:119] z of the four rows
+//   s[60:61]..s[74:75] compare masks, s76..s79 the four row characters
+// =================================================================================================
+#define SC_PRED(GI, UPI, DDI, M1, M3)                                                         \
+    "v_cmp_eq_u32_e64 " M1 ", " UPI ", " GI "\n\t"                                           \
+    "v_cmp_eq_u32_e64 " M3 ", " DDI ", " GI "\n\t"
+#define SC_SEL(GI, ZI, PI, M1, M3)                                                            \
+    "v_cmp_eq_u32_e32 vcc, " GI ", " ZI "\n\t"                                               \
+    "v_cndmask_b32_e64 " PI ", 2, 1, " M1 "\n\t"                                             \
+    "v_cndmask_b32_e64 " PI ", " PI ", 3, " M3 "\n\t"                                        \
+    "v_cndmask_b32_e64 " PI ", " PI ", 0, vcc\n\t"
+struct Rows4 { u32 h0, h1, h2, h3, p0, p1, p2, p3; };
+__device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u32 G3, u32& z, u32& blkmax, u32 a_l, u32 mm_v,
+                                                u32 xm_v, u32 ngap_v, u32 bw) {
+    Rows4 o;  // NB: no constant operands here: hipcc may give an input the same register as an in/out operand of equal value
+    asm volatile(
+        "s_bfe_u32 s76, %[bw], 0x80000\n\t"
+        "s_bfe_u32 s77, %[bw], 0x80008\n\t"
+        "s_bfe_u32 s78, %[bw], 0x80010\n\t"
+        "s_lshr_b32 s79, %[bw], 24\n\t"
+        "v_cmp_eq_u32_e64 s[60:61], s76, %[a]\n\t"
+        "v_cmp_eq_u32_e64 s[62:63], s77, %[a]\n\t"
+        "v_cmp_eq_u32_e64 s[64:65], s78, %[a]\n\t"
+        "v_cmp_eq_u32_e64 s[66:67], s79, %[a]\n\t"
+        "v_add_u32 v116, %[z], %[ngap]\n\t"
+        "v_cndmask_b32_e64 v100, %[xm], %[mm], s[60:61]\n\t"
+        "v_cndmask_b32_e64 v101, %[xm], %[mm], s[62:63]\n\t"
+        "v_cndmask_b32_e64 v102, %[xm], %[mm], s[64:65]\n\t"
+        "v_cndmask_b32_e64 v103, %[xm], %[mm], s[66:67]\n\t"
+        "v_add_u32 v117, v116, %[ngap]\n\t"
+        "v_add_u32_dpp v104, %[U], v100 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_u32_dpp v105, %[G0], v101 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_u32_dpp v106, %[G1], v102 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_u32_dpp v107, %[G2], v103 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_u32 v118, v117, %[ngap]\n\t"
+        "v_add_u32 v119, v118, %[ngap]\n\t"
+        SC_PRED("%[G0]", "%[U]", "v104", "s[60:61]", "s[62:63]")
+        SC_PRED("%[G1]", "%[G0]", "v105", "s[64:65]", "s[66:67]")
+        "v_sub_u32 %[h0], %[G0], v116\n\t"
+        SC_SEL("%[G0]", "v116", "%[p0]", "s[60:61]", "s[62:63]")
+        SC_PRED("%[G2]", "%[G1]", "v106", "s[68:69]", "s[70:71]")
+        "v_sub_u32 %[h1], %[G1], v117\n\t"
+        SC_SEL("%[G1]", "v117", "%[p1]", "s[64:65]", "s[66:67]")
+        SC_PRED("%[G3]", "%[G2]", "v107", "s[72:73]", "s[74:75]")
+        "v_sub_u32 %[h2], %[G2], v118\n\t"
+        SC_SEL("%[G2]", "v118", "%[p2]", "s[68:69]", "s[70:71]")
+        "v_sub_u32 %[h3], %[G3], v119\n\t"
+        "v_max_i32 %[bm], %[bm], %[h0]\n\t"
+        SC_SEL("%[G3]", "v119", "%[p3]", "s[72:73]", "s[74:75]")
+        "v_max3_i32 %[bm], %[bm], %[h1], %[h2]\n\t"
+        "v_max_i32 %[bm], %[bm], %[h3]\n\t"
+        "v_mov_b32 %[z], v119\n\t"
+        : [z] "+v"(z), [bm] "+v"(blkmax), [h0] "=&v"(o.h0), [h1] "=&v"(o.h1), [h2] "=&v"(o.h2), [h3] "=&v"(o.h3),
+          [p0] "=&v"(o.p0), [p1] "=&v"(o.p1), [p2] "=&v"(o.p2), [p3] "=&v"(o.p3)
+        : [U] "v"(U), [G0] "v"(G0), [G1] "v"(G1), [G2] "v"(G2), [G3] "v"(G3), [a] "v"(a_l), [mm] "v"(mm_v), [xm] "v"(xm_v),
+          [ngap] "v"(ngap_v), [bw] "s"(bw)
+        : "vcc", "scc", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
+          "s74", "s75", "s76", "s77", "s78", "s79", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+          "v116", "v117", "v118", "v119");
+    return o;
 }
 
 template <typename HT, int NS, int NC>
-__global__ void __launch_bounds__(64 * (NS * (1 + NC) + 1))
+__global__ void __launch_bounds__(64 * (NS * (1 + NC) + 2))
 sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __restrict__ seq_b,
             const unsigned char* __restrict__ bpad, FillParams p) {
-    __shared__ SysLds<NS, NC> lds;
+    __shared__ SysLds<NS> lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t M = p.M;
     const int rows = (int)p.rows;
     const int ngap = p.ngap, mm = p.mm, xm = p.xm;
-    const int T_total = (rows + SY_W + SY_U - 1) / SY_U * SY_U;  // steps 1..T_total
     const int ngroups = (p.nstrips + NS - 1) / NS;
     const u64 tag_base = p.tag_base;
     const int64_t estride = p.rows + 1;
+    const int phib = p.phi_base;
+    auto u_total = [&](int s) { return (rows + SY_W + phi_of(s, phib) + SY_U - 1) / SY_U * SY_U; };  // local steps 1..u_total
 
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        if (threadIdx.x < NS) lds.prod_t[threadIdx.x] = 0;
+        if (threadIdx.x < NS) lds.prod_u[threadIdx.x] = 0;
         if (threadIdx.x < NS * 4) lds.cons_blk[threadIdx.x / 4][threadIdx.x % 4] = ((int)(threadIdx.x % 4) < NC) ? -1 : 0x7fffffff;
         if (threadIdx.x == 0) { lds.halo_ready = 1; lds.exp_done = 0; lds.never = 0x7fffffff; }
         __syncthreads();
@@ -185,29 +460,31 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
         if (wave < NS) {
             // ================================ producer ================================
             const int ls = wave, s = s0 + ls;
+            asm volatile("; SW_PRODUCER_PATH_BEGIN ");
             if (ls < nact) {
+                const int phi = phi_of(s, phib);
+                const int UT = u_total(s);
                 const u32 j = (u32)s * SY_W + (u32)lane;
                 const bool jvalid = (int64_t)j < M;
                 const u32 a_l = (lane >= 1 && jvalid) ? (u32)seq_a[j - 1] : (u32)SY_ASENT;
                 const u32 G0v = jvalid ? (u32)((p.top ? p.top[j] : 0) + ngap * (int)j) : 0u;  // row 0 in G-space
-                u32 G1 = (lane == 0) ? G0v : 0u, G2 = 0u, m = 0u, d = 0u;
-                u32 Z = (u32)(ngap * (1 + s * SY_W));
                 const u32 mm_v = (u32)mm, xm_v = (u32)xm, ngap_v = (u32)ngap;
                 const bool lefthalo = (ls == 0);         // halo comes from the import ring
                 const bool has_right = (ls + 1 < nact);  // another producer reads my lane-63 column
                 const bool has_export = (ls + 1 == nact) && (s + 1 < p.nstrips);
-                const u32 ringbase = (u32)(size_t)&lds.ring[ls][0][0];
-                const int* left_cnt = lefthalo ? &lds.halo_ready : &lds.prod_t[ls - 1];
-                const int* right_cnt = has_right ? &lds.prod_t[ls + 1] : has_export ? &lds.exp_done : &lds.never;
-                const u32 left_addr = (u32)(size_t)left_cnt, right_addr = (u32)(size_t)right_cnt;
-                const u32 cons_addr = (u32)(size_t)&lds.cons_blk[ls][0];
-
-                auto halo_ptr = [&](int t0) -> const u32* {  // where halo(t0 + lane&15) lives
-                    const int t = t0 + (lane & 15);
-                    return lefthalo ? &lds.halo[t & (SY_RH - 1)] : &lds.ring[ls - 1][(t + SY_W - 1) & (SY_R - 1)][63];
-                };
-                auto halo_need = [&](int t0) -> int {  // counter value that makes block t0's halo readable
-                    return lefthalo ? min(t0 + SY_U - 1, rows) + 1 : min(t0 + SY_U - 1 + SY_W, T_total);
+                const u32 ringbase = (u32)(size_t)&lds.ring[ls][0];
+                const int* left_cnt = lefthalo ? &lds.halo_ready : &lds.prod_u[ls - 1];
+                const int* right_cnt = has_right ? &lds.prod_u[ls + 1] : has_export ? &lds.exp_done : &lds.never;
+                const u32 cnt_addr = (u32)(size_t)left_cnt;
+                // halo of my local step u: left strip's lane 63 at ITS local step u + hoff (hoff % 4 == 0)
+                const int hoff = lefthalo ? 0 : SY_W + phi_of(s - 1, phib) - phi;
+                const u32 hbase = lefthalo ? (u32)(size_t)&lds.halo[0] : (u32)(size_t)&lds.ring[ls - 1][63 * SY_LSTR];
+                const int hmask = lefthalo ? SY_RH - 1 : SY_R - 1;
+                auto halo_addr = [&](int u) -> u32 { return hbase + (u32)((u - 1 + hoff) & hmask) * 4u; };
+                const int left_total = lefthalo ? 0x7fffffff : u_total(s - 1);
+                // counter value that makes the halo of local steps < u_end readable
+                auto halo_need = [&](int u_end) -> int {
+                    return lefthalo ? min(u_end, rows + phi + 1) : min(u_end - 1 + hoff, left_total);
                 };
                 auto cons_rows_done = [&]() -> int {
                     const int a0 = lds_load(&lds.cons_blk[ls][0]), a1 = lds_load(&lds.cons_blk[ls][1]);
@@ -215,84 +492,100 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                     return SY_U * (min(min(a0, a1), min(a2, a3)) + 1);
                 };
 
-                // this lane's row characters: at step t it needs b[t-1-lane]; bp points at that byte for
-                // the current 64-step chunk.  16 dwords = 64 steps, loaded one chunk ahead.
+                if (phib >= 0) {
+                    // ---- fast producer (whole strip loop in one asm statement) ----
+                    const u32 wbase = ringbase + (u32)lane * (u32)SY_LSTR;
+                    const u32 voff = 2u * (u32)(p.bfront - phi - lane);           // byte offset of local step 1's character
+                    const u32 z0 = (u32)(ngap * (0 - phi + s * SY_W));            // floor of local step 0
+                    const int k1 = lefthalo ? 2 * SY_U : 2 * SY_U - 1 + hoff;     // next block readable when left >= min(u0+k1, k2)
+                    const int k2 = lefthalo ? rows + phi + 1 : left_total;
+                    const int kc = 62 - SY_R - phi;
+                    // my lane-63 entries of steps <= uc-193 get overwritten: the right-hand producer read them at its
+                    // local step (mine - 64); the exporter counts ROWS (= my step - 63 - phi)
+                    const int kr = has_right ? -(SY_R + 1) + 16 : -SY_R - phi;
+                    const int st = producer_fast(a_l, xm_v, mm_v, ngap_v, wbase, voff, z0, p.bpad16, hbase, hoff * 4, cnt_addr,
+                                                 (u32)(size_t)&lds.cons_blk[ls][0], (u32)(size_t)right_cnt, (u32)(size_t)&lds.prod_u[ls],
+                                                 UT, k1, k2, kc, kr, hmask * 4 + 3);
+                    if (st) {
+                        __hip_atomic_store((gu32*)p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return;
+                    }
+                } else {
+                // ---- generic producer (halo row / positive mismatch: needs the row-0 injection) ----
+                // this lane's row characters: at local step u it works on row u-phi-lane, i.e. b[u-phi-lane-1]
                 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-                typedef u32x4 __attribute__((aligned(1))) uint4_u;
-                const unsigned char* bp = bpad + 64 - lane;  // + (t-1)
-                u32x4 c0 = *(const uint4_u*)(bp + 0), c1 = *(const uint4_u*)(bp + 16), c2 = *(const uint4_u*)(bp + 32),
-                      c3 = *(const uint4_u*)(bp + 48);
+                typedef u32x4 __attribute__((aligned(1))) u32x4_u;
+                const unsigned char* bp = bpad + p.bfront - phi - lane - 1;  // + u
+                // prologue injection: lane l takes G0 at local step l + phi
+                u32 injv = (u32)(lane + phi);
 
-                Snap snap = {0, -1, -1, -1, -1, 0, 0u};
-                bool snap_pending = false, have_next = false;
+                // state crossing block boundaries: results of the last two steps, the floor of the last
+                // step, and the halo values of the coming block's first four steps
+                u32 G1 = (lane == 0) ? G0v : 0u, G2 = 0u;        // "step 0": only lane 0 (row 0 of the halo column) matters
+                u32 Z = (u32)(ngap * (0 - phi + s * SY_W));      // floor of local step 0
+                u32 h0 = 0, h1 = 0, h2 = 0, h3 = 0;
                 Spin spin;
+                bool have_halo = false;  // h0..h3 hold the halo of the coming block's first group
 
-                // 16 steps t0..t0+15 (KB = first step's index inside the 64-step chunk)
-                auto run_block = [&](auto PRO, auto KB, int t0, const u32x4& C) -> bool {
-                    constexpr int kb = decltype(KB)::value;
-                    if (snap_pending) snap = snap_collect();
-                    u32 Hv;
-                    if (have_next) {
-                        Hv = snap.hv;
-                    } else {
-                        while (lds_load(left_cnt) < halo_need(t0))
+                // one 16-step block: local steps u0..u0+15, KB = index of u0 inside its 64-step chunk
+                auto run_block = [&](auto PRO, auto KBt, int u0, const u32x4& C) -> bool {
+                    constexpr int KB = decltype(KBt)::value;
+                    if (!have_halo) {
+                        while (lds_load(left_cnt) < halo_need(u0 + SY_U))
                             if (spin.fail(p.abort_flag)) return false;
                         asm volatile("" ::: "memory");
-                        Hv = __hip_atomic_load(halo_ptr(t0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const u32* hp = (const u32*)(lefthalo ? (const void*)&lds.halo[(u0 - 1 + hoff) & hmask]
+                                                              : (const void*)(&lds.ring[ls - 1][63 * SY_LSTR] + 4 * ((u0 - 1 + hoff) & hmask)));
+                        h0 = __hip_atomic_load(hp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        h1 = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        h2 = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        h3 = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                    // ring slots of steps t0..t0+15 may be overwritten once their old contents (steps
-                    // t0-R ..) were consumed: rows <= t0+14-R by my consumers, halo rows <= t0+15-R-63
-                    // by the strip to the right / the exporter.  The snapshot is older, hence conservative.
-                    if (SY_U * (min(min(snap.c0, snap.c1), min(snap.c2, snap.c3)) + 1) < t0 + SY_U - 2 - SY_R)
-                        while (cons_rows_done() < t0 + SY_U - 2 - SY_R)
-                            if (spin.fail(p.abort_flag)) return false;
-                    if (snap.right < t0 + SY_U - 1 - SY_R - SY_W)
-                        while (lds_load(right_cnt) < t0 + SY_U - 1 - SY_R - SY_W)
-                            if (spin.fail(p.abort_flag)) return false;
-                    const bool next_ok = (t0 + SY_U <= T_total) && snap_pending && (snap.left >= halo_need(t0 + SY_U));
-                    const u32 waddr = ringbase + (u32)lane * 4u + (u32)((t0 - 1) & (SY_R - 1)) * 256u;
-                    const u32 next_halo_addr = (u32)(size_t)halo_ptr(t0 + SY_U);
-                    sfor<0, SY_U>([&](auto K) {
-                        constexpr int k = kb + K.value;  // index in the chunk
-                        const u32 Cw = (k / 4) % 4 == 0 ? C.x : (k / 4) % 4 == 1 ? C.y : (k / 4) % 4 == 2 ? C.z : C.w;
-                        u32 g = producer_step<k>(G1, G2, m, d, Hv, a_l, Cw, Z, ngap_v, xm_v, mm_v, waddr);
-                        // first 63 steps only: the lane whose row is 0 takes the halo-row value (kept out
-                        // of the main loop: a select here would be a third dependent op per step)
-                        if constexpr (decltype(PRO)::value) g = (lane == t0 + K.value) ? G0v : g;
-                        G2 = G1;
-                        G1 = g;
-                        if constexpr (K.value == 7) {  // mid-block: ask for the next boundary's counters
-                            snap_issue(left_addr, cons_addr, right_addr);
-                            if (next_ok) halo_issue(next_halo_addr);
-                        }
-                    });
-                    lds_store(&lds.prod_t[ls], t0 + SY_U - 1);  // in order behind the ring writes
-                    snap_pending = true;
-                    have_next = next_ok;
+                    const u32 waddr = ringbase + (u32)lane * (u32)SY_LSTR + (u32)((u0 - 1 - KB) & (SY_R - 1)) * 4u;
+                    const u32 ra1 = halo_addr(u0 + 4), ra2 = halo_addr(u0 + 8), ra3 = halo_addr(u0 + 12), ran = halo_addr(u0 + 16);
+                    int cnt;
+                    if constexpr (decltype(PRO)::value) SW_BLOCK(SW_SP, KB); else SW_BLOCK(SW_S, KB);
+                    // cnt = the left neighbour's progress as it was BEFORE the next block's halo (h0..h3)
+                    // was read: if it already covered that block, what we read is valid
+                    have_halo = (u0 + SY_U <= UT) && (cnt >= halo_need(u0 + 2 * SY_U));
+                    lds_store(&lds.prod_u[ls], u0 + SY_U - 1);  // in order behind the ring writes
                     return true;
                 };
-                auto run_chunk = [&](auto PRO, int tc) -> bool {  // 64 steps from step tc
-                    const unsigned char* nb_ = bp + (tc - 1) + 64;  // next chunk's characters
-                    const u32x4 n0 = *(const uint4_u*)(nb_ + 0), n1 = *(const uint4_u*)(nb_ + 16), n2 = *(const uint4_u*)(nb_ + 32),
-                                n3 = *(const uint4_u*)(nb_ + 48);
-                    if (!run_block(PRO, std::integral_constant<int, 0>{}, tc, c0)) return false;
-                    if (tc + 16 <= T_total && !run_block(PRO, std::integral_constant<int, 16>{}, tc + 16, c1)) return false;
-                    if (tc + 32 <= T_total && !run_block(PRO, std::integral_constant<int, 32>{}, tc + 32, c2)) return false;
-                    if (tc + 48 <= T_total && !run_block(PRO, std::integral_constant<int, 48>{}, tc + 48, c3)) return false;
+                // one 64-step chunk from local step uc (uc % 64 == 1)
+                u32x4 c0 = *(const u32x4_u*)(bp + 1), c1 = *(const u32x4_u*)(bp + 17), c2 = *(const u32x4_u*)(bp + 33), c3 = *(const u32x4_u*)(bp + 49);
+                auto run_chunk = [&](auto PRO, int uc) -> bool {
+                    // ring slots of this chunk hold steps uc-R.. : their rows (<= uc+62-R-phi) must have been
+                    // consumed, and their lane-63 entries read by the right-hand strip / the exporter
+                    while (cons_rows_done() < uc + 62 - SY_R - phi)
+                        if (spin.fail(p.abort_flag)) return false;
+                    while (lds_load(right_cnt) < uc + 63 - SY_R)
+                        if (spin.fail(p.abort_flag)) return false;
+                    const unsigned char* nb_ = bp + uc + 64;  // next chunk's characters
+                    const u32x4 n0 = *(const u32x4_u*)(nb_), n1 = *(const u32x4_u*)(nb_ + 16), n2 = *(const u32x4_u*)(nb_ + 32), n3 = *(const u32x4_u*)(nb_ + 48);
+                    if constexpr (decltype(PRO)::value) injv = (u32)(lane + phi - (uc - 1));
+                    if (!run_block(PRO, std::integral_constant<int, 0>{}, uc, c0)) return false;
+                    if (uc + 16 <= UT && !run_block(PRO, std::integral_constant<int, 16>{}, uc + 16, c1)) return false;
+                    if (uc + 32 <= UT && !run_block(PRO, std::integral_constant<int, 32>{}, uc + 32, c2)) return false;
+                    if (uc + 48 <= UT && !run_block(PRO, std::integral_constant<int, 48>{}, uc + 48, c3)) return false;
                     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
                     return true;
                 };
-                int tc = 1;
-                if (!run_chunk(std::true_type{}, tc)) return;   // steps 1..64 contain every row-0 injection
-                for (tc += 64; tc <= T_total; tc += 64)
-                    if (!run_chunk(std::false_type{}, tc)) return;
+                int uc = 1;
+                if (!run_chunk(std::true_type{}, uc)) return;  // local steps 1..128 contain every row-0 injection
+                uc += 64;
+                if (uc <= UT) { if (!run_chunk(std::true_type{}, uc)) return; uc += 64; }
+                for (; uc <= UT; uc += 64)
+                    if (!run_chunk(std::false_type{}, uc)) return;
+                }
             }
+            asm volatile("; SW_PRODUCER_PATH_END");
         } else if (wave < NS + NS * NC) {
             // ================================ consumer ================================
             const int ls = (wave - NS) % NS, ci = (wave - NS) / NS, s = s0 + ls;
             if (ls < nact && (p.debug_flags & 2)) {
                 lds_store(&lds.cons_blk[ls][ci], 1 << 24);  // timing experiment: producer alone
             } else if (ls < nact) {
+                const int phi = phi_of(s, phib);
                 const u32 j = (u32)s * SY_W + (u32)lane;
                 const bool jvalid = (int64_t)j < M;
                 const bool store_ok = jvalid && (lane >= 1 || s == 0) && !(p.debug_flags & 1);
@@ -307,110 +600,149 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                     H[j] = (HT)(p.top ? p.top[j] : 0);
                     P[j] = 0;
                 }
-                int bestv = store_ok ? 0 : 0x7fffffff, bestrow = 0;
+                int bestv = 0, bestblk = 0;   // arg-max: best value and the first of MY blocks that reached it
+                const u32 a_lu = (u32)a_l, mm_v = (u32)mm, xm_v = (u32)xm, ngap_v = (u32)ngap;
                 const int nblk = (rows + SY_U - 1) / SY_U;
+                const u32* myring = (const u32*)&lds.ring[ls][lane * SY_LSTR];
                 int snap_prod = 0;
                 Spin spin;
                 for (int q = ci; q < nblk; q += NC) {
                     const int r0 = q * SY_U + 1;
                     const int nb = min(SY_U, rows - r0 + 1);
-                    const int need = r0 + nb - 1 + SY_W;  // the step that completes row r0+nb-1
+                    const int need = r0 + nb - 1 + SY_W + phi;  // the local step that completes row r0+nb-1
                     if (snap_prod < need)
-                        while ((snap_prod = lds_load(&lds.prod_t[ls])) < need)
+                        while ((snap_prod = lds_load(&lds.prod_u[ls])) < need)
                             if (spin.fail(p.abort_flag)) return;
-                    // rows r0-1 .. r0+15 of the ring, read along the skew: row r, lane l sits in slot r+l-1
                     asm volatile("" ::: "memory");
-                    u32 slot = (u32)(r0 - 2 + lane);
+                    // rows r0-1 .. r0+15 along the skew: row r of lane l is step r+l+phi, ring entry (step-1) mod R
+                    const u32 e0 = (u32)(r0 - 2 + lane + phi);
                     u32 gv[SY_U + 1];
+                    if ((((u32)(r0 - 2 + phi) & (SY_R - 1)) + 63 + SY_U) < (u32)SY_R) {
+                        const u32* q0 = myring + (e0 & (SY_R - 1));  // no lane wraps inside this block
 #pragma unroll
-                    for (int k = 0; k <= SY_U; ++k, ++slot)
-                        gv[k] = __hip_atomic_load(&lds.ring[ls][slot & (SY_R - 1)][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    snap_prod = lds_load(&lds.prod_t[ls]);  // looked at again one block later
-                    int U = (r0 == 1) ? G0v : (int)gv[0];
-                    // this block's b characters
-                    u32 bw[4];
-                    if (nb == SY_U) {
-                        const uint4 w = *reinterpret_cast<const uint4*>(seq_b + (r0 - 1));
-                        bw[0] = w.x; bw[1] = w.y; bw[2] = w.z; bw[3] = w.w;
+                        for (int k = 0; k <= SY_U; ++k) gv[k] = __hip_atomic_load(q0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
-                        bw[0] = bw[1] = bw[2] = bw[3] = 0;
-                        for (int r = 0; r < nb; ++r) bw[r >> 2] |= (u32)seq_b[r0 - 1 + r] << (8 * (r & 3));
+#pragma unroll
+                        for (int k = 0; k <= SY_U; ++k)
+                            gv[k] = __hip_atomic_load(myring + ((e0 + k) & (SY_R - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+                    snap_prod = lds_load(&lds.prod_u[ls]);  // looked at again one block later
+                    if (r0 == 1) gv[0] = (u32)G0v;
                     const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)(H + (int64_t)r0 * M), 0, 0x7FFFFF00, 0x00020000);
                     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(P + (int64_t)r0 * M), 0, 0x7FFFFF00, 0x00020000);
                     const u32 rowH = (u32)(M * (int64_t)sizeof(HT)), rowP = (u32)(M * 4);
-                    auto do_row = [&](int k) {
-                        const int g = (int)gv[k + 1];
-                        const int b_i = (int)((bw[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                        const int D = __builtin_amdgcn_update_dpp(0, U, 0x138, 0xF, 0xF, false);  // G[r-1][j-1]
-                        const int dd = D + ((a_l == b_i) ? mm : xm);
-                        const int z = cz + ngap * (r0 + k);
-                        const int h = g - z;
-                        const int pred = (g == z) ? 0 : (dd == g) ? 3 : (U == g) ? 1 : 2;  // serial_smithW.c:204-234
+                    auto store_row = [&](int k, u32 h, u32 pr) {
                         if constexpr (sizeof(HT) == 8) {
                             typedef int v2i __attribute__((ext_vector_type(2)));
-                            v2i hv; hv.x = h; hv.y = h >> 31;
+                            v2i hv; hv.x = (int)h; hv.y = (int)h >> 31;
                             __builtin_amdgcn_raw_buffer_store_b64(hv, rH, voffH, (int)(rowH * (u32)k), 0);
                         } else {
-                            __builtin_amdgcn_raw_buffer_store_b32(h, rH, voffH, (int)(rowH * (u32)k), 0);
+                            __builtin_amdgcn_raw_buffer_store_b32((int)h, rH, voffH, (int)(rowH * (u32)k), 0);
                         }
-                        __builtin_amdgcn_raw_buffer_store_b32(pred, rP, voffP, (int)(rowP * (u32)k), 0);
-                        if (h > bestv) { bestv = h; bestrow = r0 + k; }
-                        U = g;
+                        __builtin_amdgcn_raw_buffer_store_b32((int)pr, rP, voffP, (int)(rowP * (u32)k), 0);
                     };
-                    if (nb == SY_U) {  // one basic block: the 16 rows are independent, hipcc interleaves them
-                        sfor<0, SY_U>([&](auto K) { do_row(K.value); });
-                    } else {
-                        sfor<0, SY_U>([&](auto K) { if (K.value < nb) do_row(K.value); });
+                    u32 blkmax = 0;
+                    if (nb == SY_U) {
+                        const uint4 w = *reinterpret_cast<const uint4*>(seq_b + (r0 - 1));  // this block's 16 row characters
+                        const u32 bw[4] = {w.x, w.y, w.z, w.w};
+                        u32 z = (u32)(cz + ngap * (r0 - 1));
+                        sfor<0, 4>([&](auto Q) {
+                            constexpr int k = Q.value * 4;
+                            const Rows4 o = consumer_rows4(gv[k], gv[k + 1], gv[k + 2], gv[k + 3], gv[k + 4], z, blkmax, a_lu, mm_v, xm_v,
+                                                           ngap_v, bw[Q.value]);
+                            store_row(k, o.h0, o.p0); store_row(k + 1, o.h1, o.p1); store_row(k + 2, o.h2, o.p2); store_row(k + 3, o.h3, o.p3);
+                        });
+                    } else {  // the last, partial block of the matrix: plain per-row code
+                        for (int k = 0; k < nb; ++k) {
+                            int g = 0, U = 0;
+                            sfor<0, SY_U>([&](auto K) { if (K.value == k) { g = (int)gv[K.value + 1]; U = (int)gv[K.value]; } });
+                            const int b_i = (int)seq_b[r0 - 1 + k];
+                            const int D = __builtin_amdgcn_update_dpp(0, U, 0x138, 0xF, 0xF, false);  // G[r-1][j-1]
+                            const int dd = D + ((a_l == b_i) ? mm : xm);
+                            const int zz = cz + ngap * (r0 + k);
+                            const int h = g - zz;
+                            const int pred = (g == zz) ? 0 : (dd == g) ? 3 : (U == g) ? 1 : 2;  // serial_smithW.c:204-234
+                            store_row(k, (u32)h, (u32)pred);
+                            blkmax = (u32)max((int)blkmax, h);
+                        }
                     }
+                    if ((int)blkmax > bestv) { bestv = (int)blkmax; bestblk = q; }
                     lds_store(&lds.cons_blk[ls][ci], q);
                 }
+                // arg-max: the lowest row of block `bestblk` holding bestv in my column (re-read what this wave stored)
                 if (store_ok && bestv > 0) {
+                    __builtin_amdgcn_s_waitcnt(0);  // my own stores have reached L2
+                    int bestrow = 0;
+                    for (int k = SY_U - 1; k >= 0; --k) {
+                        const int r = bestblk * SY_U + 1 + k;
+                        if (r <= rows && (int)__builtin_nontemporal_load(&H[(int64_t)r * M + j]) == bestv) bestrow = r;
+                    }
                     const u64 idx = (u64)bestrow * (u64)M + (u64)j;
                     atomicMax(p.result_key, ((u64)(u32)bestv << 40) | (SW_KEY_IDX_MASK - idx));
                 }
             }
         } else {
             // ================================= helper ==================================
-            // import: edge column of strip s0-1 (HBM granules, or column 0 synthesised) -> lds.halo
+            // import: edge column of strip s0-1 (HBM granules; column 0 / row 0 synthesised) -> lds.halo,
+            //         indexed by strip s0's local step: row t lives at entry (t + phi0 - 1) mod RH
             // export: lane-63 column of the group's last strip -> HBM granules for the next group
             const int slast = s0 + nact - 1;
             const bool do_export = (slast + 1 < p.nstrips);
-            const int k16 = lane & 15;
-            int imp = 1, exp = 1;
+            const int phi0 = phi_of(s0, phib), phil = phi_of(slast, phib);
+            const u32 halo_row0 = (u32)((p.top ? p.top[(int64_t)s0 * SY_W] : 0) + ngap * s0 * SY_W);
+            // import starts at row 0 (the diagonal neighbour of row 1); with the fast producers at the row of
+            // strip s0's local step 1: the cells above the matrix hold the H == 0 floor there
+            int imp = (phib >= 0) ? 1 - phi0 : 0, exp = 1;
             Spin spin;
-            while (imp <= rows || (do_export && exp <= rows)) {
+            auto edge_val = [&](int r, bool& ok) -> u32 {  // G of (row r, column 63*s0): the halo of strip s0
+                ok = true;
+                if (r <= 0) return (r == 0) ? halo_row0 : (u32)(ngap * (r + s0 * SY_W));  // above the matrix: H == 0 floor
+                if (s0 == 0) return (u32)(ngap * r);                                        // column 0: H == 0
+                const u64 gr = __hip_atomic_load((gu64*)(p.edge + (int64_t)(s0 - 1) * estride + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (gr >> 32) == (tag_base | (u64)r);
+                return (u32)gr;
+            };
+            const bool importer = (wave == NS + NS * NC), exporter = !importer;  // one wave each
+            while ((importer && imp <= rows) || (exporter && do_export && exp <= rows)) {
                 bool progressed = false;
-                if (imp <= rows && imp + SY_U - 1 - SY_RH <= lds_load(&lds.prod_t[0])) {
-                    const int n = min(SY_U, rows - imp + 1);
-                    const int r = min(imp + k16, rows);
-                    u32 val;
-                    bool ok = true;
-                    if (s0 == 0) {
-                        val = (u32)(ngap * r);  // column 0: H == 0
-                    } else {
-                        const u64 gr = __hip_atomic_load((gu64*)(p.edge + (int64_t)(s0 - 1) * estride + r), __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
-                        ok = (gr >> 32) == (tag_base | (u64)r);
-                        val = (u32)gr;
+                if (importer && imp <= rows) {
+                    // halo[] holds RH steps and strip s0's producer has consumed every step <= its progress:
+                    // rows < lim may be written.  Up to 4 x 64 rows per round trip to HBM/L2.
+                    const int lim = min(rows + 1, lds_load(&lds.prod_u[0]) - phi0 + SY_RH - 2 * SY_U);
+                    int base = imp;
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4) {
+                        const int r = imp + b4 * 64 + lane;
+                        bool ok = false;
+                        u32 val = 0;
+                        if (r < lim) val = edge_val(r, ok);
+                        const u64 okm = __ballot(ok);
+                        const int npre = (okm == ~0ull) ? 64 : __builtin_ctzll(~okm);  // leading run of valid rows
+                        if (base == imp + b4 * 64 && npre > 0) {                       // contiguous with what is imported
+                            if (lane < npre) __hip_atomic_store(&lds.halo[(r + phi0 - 1) & (SY_RH - 1)], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            base += npre;
+                        }
                     }
-                    if (__all(ok)) {
-                        if (lane < n) __hip_atomic_store(&lds.halo[(imp + lane) & (SY_RH - 1)], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (base > imp) {
                         asm volatile("" ::: "memory");  // LDS executes a wave's ops in order: data before counter
-                        imp += n;
-                        lds_store(&lds.halo_ready, imp);
+                        imp = base;
+                        lds_store(&lds.halo_ready, imp + phi0);  // local steps < imp+phi0 are in halo[]
                         progressed = true;
                     }
                 }
-                if (do_export && exp <= rows) {
-                    const int n = min(SY_U, rows - exp + 1);
-                    if (lds_load(&lds.prod_t[nact - 1]) >= exp + n - 1 + SY_W) {
-                        const int r = min(exp + k16, rows);
+                if (exporter && do_export && exp <= rows) {
+                    // rows whose lane-63 value the last producer has written: step r+63+phi <= its progress
+                    const int avail = lds_load(&lds.prod_u[nact - 1]) - SY_W - phil;
+                    const int n = min(64, min(rows, avail) - exp + 1);
+                    if (n > 0) {
                         asm volatile("" ::: "memory");
-                        const u32 v = __hip_atomic_load(&lds.ring[nact - 1][(r + SY_W - 1) & (SY_R - 1)][63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (lane < n)
+                        const int r = exp + lane;
+                        const u32* e = (const u32*)&lds.ring[nact - 1][63 * SY_LSTR];
+                        if (lane < n) {
+                            const u32 v = __hip_atomic_load(e + ((r + SY_W + phil - 1) & (SY_R - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             __hip_atomic_store((gu64*)(p.edge + (int64_t)slast * estride + r), ((tag_base | (u64)r) << 32) | (u64)v,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         exp += n;
                         lds_store(&lds.exp_done, exp - 1);
                         progressed = true;
@@ -418,6 +750,8 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                 }
                 if (!progressed && spin.fail(p.abort_flag)) return;
             }
+            if (exporter && do_export) lds_store(&lds.exp_done, 0x7fffffff);
+            if (importer) lds_store(&lds.halo_ready, 0x7fffffff);
         }
         __syncthreads();
     }
@@ -431,14 +765,19 @@ SW_INST(2, 3)
 SW_INST(2, 4)
 SW_INST(1, 2)
 SW_INST(1, 4)
-
 #undef SW_INST
 
-// bpad[64 + i] = b[i], zero padded on both sides: producer lane l reads b[t-1-l] for steps t that
-// reach 63 rows above and ~130 rows below the matrix (those cells are never stored).
-__global__ void sw_pad_b(const unsigned char* __restrict__ b, int64_t rows, unsigned char* __restrict__ bpad, int64_t n) {
+// bpad[front + i] = b[i] (bytes, zero padded) and bpad16[front + i] = b[i] (16-bit, padded with the
+// never-matching 0x100): producer lane l reads b[u-phi-l-1] for steps that reach phi+63 rows above and
+// ~200 rows below the matrix (those cells are never stored).
+__global__ void sw_pad_b(const unsigned char* __restrict__ b, int64_t rows, int64_t front, unsigned char* __restrict__ bpad,
+                         unsigned short* __restrict__ bpad16, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) bpad[i] = (i >= 64 && i - 64 < rows) ? b[i - 64] : (unsigned char)0;
+    if (i < n) {
+        const bool in = (i >= front && i - front < rows);
+        bpad[i] = in ? b[i - front] : (unsigned char)0;
+        bpad16[i] = in ? (unsigned short)b[i - front] : (unsigned short)0x100;  // 0x100 never equals a character
+    }
 }
 
 }  // namespace swk
