@@ -19,7 +19,8 @@ nproc >> gpurun_out/ci.log; lscpu | grep "Model name" >> gpurun_out/ci.log
 step smoke 300 python __graft_entry__.py smoke
 step pytest_gpu 600 python -m pytest tests -m gpu -x -q
 step bench 400 python bench.py --steps 10 --warmup 2
-for w in 1 2 8; do step bench_wpb$w 200 python bench.py --steps 5 --warmup 1 --no-cpu --wpb $w; done
+step bench_strip_scan 200 python bench.py --steps 5 --warmup 1 --no-cpu --engine 1
+step bench_h64_32k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 32768 --rows 32768 --h64
 export TMPDIR=/tmp
 step rocprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 5 --warmup 1 --no-cpu
 find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -8 "$f"; done

@@ -28,9 +28,10 @@ struct sw_ctx {
     unsigned char* d_cb = nullptr;      // systolic engine: zero-padded copy of b (sw_pad_b)
     size_t cb_cap = 0;
     int64_t opt_debug = 0;
+    int64_t opt_dbg_ptr = 0;
     int64_t opt_engine = 0;             // 0 = systolic producer/consumer pipeline, 1 = strip_scan (row scan)
     int64_t opt_strips_per_group = 2;   // systolic: producer waves (strips) per workgroup
-    int64_t opt_consumers = 2;          // systolic: consumer waves per strip
+    int64_t opt_consumers = 4;          // systolic: consumer waves per strip
     int64_t opt_waves_per_block = 4;
     int64_t opt_max_blocks = 0;         // 0 -> 2 * CUs
     int64_t last_grid = 0, last_strips = 0;
@@ -73,8 +74,9 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     }
     if (!strcmp(name, "max_blocks")) { c->opt_max_blocks = v < 0 ? 0 : v; return SW_OK; }
     if (!strcmp(name, "strips_per_group")) { c->opt_strips_per_group = v ? v : 2; return SW_OK; }
-    if (!strcmp(name, "consumers")) { c->opt_consumers = v ? v : 2; return SW_OK; }
+    if (!strcmp(name, "consumers")) { c->opt_consumers = v ? v : 4; return SW_OK; }
     if (!strcmp(name, "debug_flags")) { c->opt_debug = v; return SW_OK; }
+    if (!strcmp(name, "debug_buf")) { c->opt_dbg_ptr = v; return SW_OK; }
     if (!strcmp(name, "engine")) {
         if (v != 0 && v != 1) { set_err("engine must be 0 (systolic) or 1 (strip_scan)"); return SW_EINVAL; }
         c->opt_engine = v;
@@ -160,6 +162,7 @@ int sw_fill_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, in
         p.result_key = c->d_key; p.abort_flag = (unsigned int*)(c->d_key + 1);
         p.nstrips = (int)S;
         p.debug_flags = (int)c->opt_debug;
+        p.dbg = (unsigned long long*)(uintptr_t)c->opt_dbg_ptr;
         const unsigned char* ua = (const unsigned char*)d_a;
         const unsigned char* ub = (const unsigned char*)d_b;
         if (systolic) {

@@ -24,6 +24,7 @@ struct FillParams {
     int phi_base;              // systolic: >= 0 -> fast producers, phi = phi_base - s; < 0 -> generic
     int bfront;                // systolic: index of b[0] inside bpad / bpad16
     const unsigned short* bpad16;
+    unsigned long long* dbg;   // optional: per strip {start, end} s_memrealtime stamps of its producer (experiments)
     int debug_flags;           // bit0: drop the H/P stores (timing experiments only)
     int nstrips;               // strip_scan: ceil(cols/64); systolic: ceil(cols/63)
 };

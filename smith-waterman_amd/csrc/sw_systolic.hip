@@ -457,6 +457,14 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
         const int s0 = grp * NS;
         const int nact = min(NS, p.nstrips - s0);  // active strips of this group
 
+        // Role of each wave.  Waves are dealt to the four SIMDs cyclically, so waves w, w+4, w+8 share a
+        // SIMD: with NS == 2 the two mostly-sleeping helper waves take slots 4 and 5, i.e. the SIMDs of the
+        // two producers (waves 0 and 1), and every consumer wave shares at most with one producer.
+        constexpr int NWAVES = NS * (1 + NC) + 2;
+        constexpr bool helpers_mid = (NS == 2 && NWAVES > 6);
+        const int h_imp = helpers_mid ? 4 : NWAVES - 2, h_exp = helpers_mid ? 5 : NWAVES - 1;
+        const bool is_helper = (wave == h_imp || wave == h_exp);
+        const int cw = helpers_mid ? (wave < 4 ? wave - NS : wave - NS - 2) : wave - NS;  // consumer ordinal 0..NS*NC-1
         if (wave < NS) {
             // ================================ producer ================================
             const int ls = wave, s = s0 + ls;
@@ -492,6 +500,7 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                     return SY_U * (min(min(a0, a1), min(a2, a3)) + 1);
                 };
 
+                if (p.dbg && lane == 0) p.dbg[2 * s] = __builtin_amdgcn_s_memrealtime();
                 if (phib >= 0) {
                     // ---- fast producer (whole strip loop in one asm statement) ----
                     const u32 wbase = ringbase + (u32)lane * (u32)SY_LSTR;
@@ -506,6 +515,7 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                     const int st = producer_fast(a_l, xm_v, mm_v, ngap_v, wbase, voff, z0, p.bpad16, hbase, hoff * 4, cnt_addr,
                                                  (u32)(size_t)&lds.cons_blk[ls][0], (u32)(size_t)right_cnt, (u32)(size_t)&lds.prod_u[ls],
                                                  UT, k1, k2, kc, kr, hmask * 4 + 3);
+                    if (p.dbg && lane == 0) p.dbg[2 * s + 1] = __builtin_amdgcn_s_memrealtime();
                     if (st) {
                         __hip_atomic_store((gu32*)p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         return;
@@ -579,9 +589,9 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                 }
             }
             asm volatile("; SW_PRODUCER_PATH_END");
-        } else if (wave < NS + NS * NC) {
+        } else if (!is_helper) {
             // ================================ consumer ================================
-            const int ls = (wave - NS) % NS, ci = (wave - NS) / NS, s = s0 + ls;
+            const int ls = cw % NS, ci = cw / NS, s = s0 + ls;
             if (ls < nact && (p.debug_flags & 2)) {
                 lds_store(&lds.cons_blk[ls][ci], 1 << 24);  // timing experiment: producer alone
             } else if (ls < nact) {
@@ -702,7 +712,7 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                 ok = (gr >> 32) == (tag_base | (u64)r);
                 return (u32)gr;
             };
-            const bool importer = (wave == NS + NS * NC), exporter = !importer;  // one wave each
+            const bool importer = (wave == h_imp), exporter = !importer;  // one wave each
             while ((importer && imp <= rows) || (exporter && do_export && exp <= rows)) {
                 bool progressed = false;
                 if (importer && imp <= rows) {
@@ -710,16 +720,22 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                     // rows < lim may be written.  Up to 4 x 64 rows per round trip to HBM/L2.
                     const int lim = min(rows + 1, lds_load(&lds.prod_u[0]) - phi0 + SY_RH - 2 * SY_U);
                     int base = imp;
+                    u32 vals[4];
+                    bool oks[4];
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4) {   // all four loads in flight before anything looks at them
+                        const int r = imp + b4 * 64 + lane;
+                        oks[b4] = false;
+                        vals[b4] = 0;
+                        if (r < lim) vals[b4] = edge_val(r, oks[b4]);
+                    }
 #pragma unroll
                     for (int b4 = 0; b4 < 4; ++b4) {
                         const int r = imp + b4 * 64 + lane;
-                        bool ok = false;
-                        u32 val = 0;
-                        if (r < lim) val = edge_val(r, ok);
-                        const u64 okm = __ballot(ok);
+                        const u64 okm = __ballot(oks[b4]);
                         const int npre = (okm == ~0ull) ? 64 : __builtin_ctzll(~okm);  // leading run of valid rows
                         if (base == imp + b4 * 64 && npre > 0) {                       // contiguous with what is imported
-                            if (lane < npre) __hip_atomic_store(&lds.halo[(r + phi0 - 1) & (SY_RH - 1)], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (lane < npre) __hip_atomic_store(&lds.halo[(r + phi0 - 1) & (SY_RH - 1)], vals[b4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             base += npre;
                         }
                     }
