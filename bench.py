@@ -126,6 +126,13 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
+        traffic = None   # HBM bytes per launch from the PMC passes (scripts/gpu_pmc.sh), when they exist for this workload
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if pm["workload"] == f"{cols}x{rows} {'int64' if args.h64 else 'int32'} engine={'systolic' if args.engine == 0 else 'strip_scan'}":
+                traffic = pm["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         cells = cols * rows
         bytes_per_cell = 12 if args.h64 else 8       # mandatory H + P output only
         avg_ms = sum(kern_ms) / len(kern_ms)
@@ -140,7 +147,7 @@ def main():
                        "per_gpu": "one independent pair per GPU", "max_pos": res["max_pos"], "max_score": res["max_score"],
                        "grid": eng.get_option("last_grid"), "strips": eng.get_option("last_strips")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "sw_systolic" if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
                          "algorithmic_bytes_per_cell": bytes_per_cell},
         }
