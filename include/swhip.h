@@ -78,6 +78,26 @@ int sw_fill_device(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, 
                    const sw_scores* scores, void* d_H, int h_elem_bytes, int32_t* d_P,
                    const int32_t* d_top, sw_result* d_result, void* stream);
 
+/* Tile of a bigger matrix (multi-GPU row bands x column chunks).  d_H / d_P point at the
+ * tile's corner cell (row above / column left of its first cell) inside matrices of row stride
+ * `row_stride` elements; d_top: cols+1 H values of the row above (NULL = zeros), d_left: rows+1 H values
+ * of the column to the left (NULL = zeros; d_left[0] is the corner), d_right (optional): receives the
+ * rows+1 H values of the tile's last column = the next tile's d_left.  The tile's last row is the next
+ * band's d_top.  d_result->max_pos is relative to the corner with the full row stride.
+ * Row 0 / column 0 of the tile are not re-written when they belong to a neighbour (P untouched). */
+int sw_fill_tile_device(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, int64_t rows,
+                        const sw_scores* scores, void* d_H, int h_elem_bytes, int32_t* d_P, int64_t row_stride,
+                        const int32_t* d_top, const int32_t* d_left, int32_t* d_right, sw_result* d_result,
+                        void* stream);
+
+/* Batch of npairs independent cols x rows problems (BASELINE config 5): pair k reads a at
+ * d_a + k*a_stride and b at d_b + k*b_stride (b_stride a multiple of 16), writes d_results[k] and, when
+ * d_H/d_P are given (both or neither), its matrices at offset k*(rows+1)*(cols+1).  Without matrices the
+ * fill is score-only: max_score is exact, max_pos is the first row of the 16-row block holding it. */
+int sw_batch_device(sw_ctx* ctx, const char* d_a, int64_t a_stride, int64_t cols, const char* d_b, int64_t b_stride,
+                    int64_t rows, int64_t npairs, const sw_scores* scores, int32_t* d_H, int32_t* d_P,
+                    sw_result* d_results, void* stream);
+
 /* Host-buffer convenience wrapper around sw_fill_device (alloc, H2D, fill, D2H, sync).
  * H, P: caller-owned int32 (rows+1)*(cols+1); either may be NULL to skip its copy-out. */
 int sw_fill_host(sw_ctx* ctx, const char* a, int64_t cols, const char* b, int64_t rows,

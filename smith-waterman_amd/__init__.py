@@ -51,6 +51,8 @@ ABI = {
     "sw_create": (_i32, [_i32, ctypes.POINTER(_vp)]),
     "sw_destroy": (None, [_vp]),
     "sw_fill_device": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _i32, _vp, _vp, _vp, _vp]),
+    "sw_fill_tile_device": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "sw_batch_device": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, ctypes.POINTER(_Scores), _vp, _vp, _vp, _vp]),
     "sw_fill_host": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result)]),
     "sw_traceback_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "sw_traceback_host": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
@@ -213,6 +215,50 @@ class Engine:
         self.fill_into(out, d_a, d_b, scores, top)
         self.synchronize()
         return out
+
+    def fill_tile(self, H, P, i0: int, j0: int, trows: int, tcols: int, d_a, d_b, res, scores=DEFAULT_SCORES,
+                  top=None, left=None, right=None):
+        """Asynchronous fill of the tile rows i0+1..i0+trows x cols j0+1..j0+tcols of the matrices H, P
+        (torch CUDA tensors with row stride H.shape[1]).  d_a / d_b: the FULL padded device sequences;
+        top: int32 tensor with tcols+1 H values of row i0 (or None), left: trows+1 values of column j0,
+        right: output tensor (trows+1) for column j0+tcols.  i0 must be a multiple of 16."""
+        t = self.torch
+        assert i0 % 16 == 0, "tile rows must start at a multiple of 16 (16-byte aligned b window)"
+        sc = _Scores(*scores)
+        stride = H.shape[1]
+        hb = 8 if H.dtype == t.int64 else 4
+        corner = i0 * stride + j0
+        _check(lib().sw_fill_tile_device(
+            self._h, d_a.data_ptr() + j0, tcols, d_b.data_ptr() + i0, trows, ctypes.byref(sc),
+            H.data_ptr() + corner * hb, hb, P.data_ptr() + corner * 4, stride,
+            top.data_ptr() if top is not None else None, left.data_ptr() if left is not None else None,
+            right.data_ptr() if right is not None else None, res.data_ptr(), self._stream()))
+
+    def batch(self, a_all, b_all, scores=DEFAULT_SCORES, store: bool = False):
+        """npairs independent problems (BASELINE config 5).  a_all: (npairs, cols) uint8, b_all: (npairs, rows).
+        Returns (results[npairs,3] int64 tensor, H, P) with H/P None unless store."""
+        t = self.torch
+        a_all = np.ascontiguousarray(a_all, np.uint8)
+        b_all = np.ascontiguousarray(b_all, np.uint8)
+        npairs, cols = a_all.shape
+        rows = b_all.shape[1]
+        dev = f"cuda:{self.device}"
+        bstr = (rows + 15) // 16 * 16
+        d_a = t.from_numpy(a_all).to(dev)
+        bpad = np.zeros((npairs, bstr), np.uint8)
+        bpad[:, :rows] = b_all
+        d_b = t.from_numpy(bpad).to(dev)
+        res = t.zeros((npairs, 3), dtype=t.int64, device=dev)
+        H = P = None
+        if store:
+            H = t.empty((npairs, rows + 1, cols + 1), dtype=t.int32, device=dev)
+            P = t.empty((npairs, rows + 1, cols + 1), dtype=t.int32, device=dev)
+        sc = _Scores(*scores)
+        _check(lib().sw_batch_device(self._h, d_a.data_ptr(), cols, cols, d_b.data_ptr(), bstr, rows, npairs, ctypes.byref(sc),
+                                     H.data_ptr() if store else None, P.data_ptr() if store else None, res.data_ptr(),
+                                     self._stream()))
+        self.synchronize()
+        return res, H, P
 
     def traceback(self, out: Fill, max_pos: int | None = None, want_path: bool = True):
         """backtrack() on the device P (negates the path in place). Returns the path indices."""

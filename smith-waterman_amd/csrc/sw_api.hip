@@ -25,6 +25,7 @@ struct sw_ctx {
     unsigned long long* d_edge = nullptr;
     size_t edge_cap = 0;                // granules
     unsigned long long* d_key = nullptr; // [0] = arg-max key, [1] low word = abort flag
+    unsigned long long* d_keys = nullptr; size_t keys_cap = 0;  // batch: one key per pair
     unsigned char* d_cb = nullptr;      // systolic engine: zero-padded copy of b (sw_pad_b)
     size_t cb_cap = 0;
     int64_t opt_debug = 0;
@@ -62,6 +63,7 @@ void sw_destroy(sw_ctx* c) {
     if (c->d_edge) (void)hipFree(c->d_edge);
     if (c->d_key) (void)hipFree(c->d_key);
     if (c->d_cb) (void)hipFree(c->d_cb);
+    if (c->d_keys) (void)hipFree(c->d_keys);
     delete c;
 }
 
@@ -116,105 +118,175 @@ static int check_dims(int64_t cols, int64_t rows, const sw_scores* sc) {
     return SW_OK;
 }
 
-int sw_fill_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
-                   void* d_H, int h_elem_bytes, int32_t* d_P, const int32_t* d_top, sw_result* d_result, void* stream_) {
-    static const sw_scores kDefault = {3, -3, -2};  // serial_smithW.c:59-61
-    const sw_scores* sc = scores ? scores : &kDefault;
-    if (!c || !d_H || !d_P || !d_result || (h_elem_bytes != 4 && h_elem_bytes != 8)) {
-        set_err("sw_fill_device: bad argument");
-        return SW_EINVAL;
+// One launch of the fill: a whole matrix, a tile of a bigger matrix (row stride, halo row/column) or a
+// batch of independent problems.
+struct FillJob {
+    const char* d_a; int64_t cols; const char* d_b; int64_t rows;
+    void* d_H; int h_elem_bytes; int32_t* d_P; int64_t stride;
+    const int32_t* d_top; const int32_t* d_left; int32_t* d_right;
+    int64_t npairs; int64_t a_pstride, b_pstride, hp_pstride;
+    unsigned long long* d_keys;   // npairs packed arg-max keys (device)
+};
+
+static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStream_t stream) {
+    const int64_t cols = j.cols, rows = j.rows;
+    const bool systolic = (c->opt_engine == 0);
+    const bool tile_features = j.d_left || j.d_right || j.stride != cols + 1 || j.npairs != 1 || !j.d_H;
+    if (!systolic && tile_features) { set_err("tiles / batches need the systolic engine (engine 0)"); return SW_EINVAL; }
+    const int64_t S = systolic ? (cols + 62) / 63 : (cols + 63) / 64;
+    if (((uintptr_t)j.d_b & 15) != 0 || (j.b_pstride & 15) != 0) { set_err("d_b (and the batch stride of b) must be 16-byte aligned"); return SW_EINVAL; }
+    const size_t need = (size_t)S * (size_t)(rows + 1) * (size_t)j.npairs;
+    if (need > c->edge_cap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c->d_edge) HIP_TRY(hipFree(c->d_edge));
+        c->d_edge = nullptr; c->edge_cap = 0;
+        if (hipMalloc((void**)&c->d_edge, need * 8) != hipSuccess) { set_err("workspace allocation of %zu bytes failed", need * 8); return SW_ENOMEM; }
+        c->edge_cap = need;
+        HIP_TRY(hipMemsetAsync(c->d_edge, 0, need * 8, stream));
+        c->epoch = 0;
     }
-    if (int rc = check_dims(cols, rows, sc)) return rc;
-    if ((cols > 0 && !d_a) || (rows > 0 && !d_b)) { set_err("sw_fill_device: NULL sequence"); return SW_EINVAL; }
-    hipStream_t stream = (hipStream_t)stream_;
-    HIP_TRY(hipSetDevice(c->device));
-    const int64_t M = cols + 1;
-    HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream));
-    if (cols == 0 || rows == 0) {
-        // no interior cell: H (= halo row / zero column) and P are all boundary
-        HIP_TRY(hipMemsetAsync(d_H, 0, (size_t)(M * (rows + 1)) * h_elem_bytes, stream));
-        HIP_TRY(hipMemsetAsync(d_P, 0, (size_t)(M * (rows + 1)) * 4, stream));
-        if (d_top && h_elem_bytes == 4) HIP_TRY(hipMemcpyAsync(d_H, d_top, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
-        if (d_top && h_elem_bytes == 8) { set_err("sw_fill_device: top halo with an empty int64 band is unsupported"); return SW_EINVAL; }
-    } else {
-        const bool systolic = (c->opt_engine == 0);
-        const int64_t S = systolic ? (cols + 62) / 63 : (cols + 63) / 64;
-        if (((uintptr_t)d_b & 15) != 0) { set_err("sw_fill_device: d_b must be 16-byte aligned"); return SW_EINVAL; }
-        const size_t need = (size_t)S * (size_t)(rows + 1);
-        if (need > c->edge_cap) {
+    if (++c->epoch >= 4096) {  // 12-bit tag wrapped: stale tags could match again, wipe them
+        HIP_TRY(hipMemsetAsync(c->d_edge, 0, c->edge_cap * 8, stream));
+        c->epoch = 1;
+    }
+    swk::FillParams p;
+    memset(&p, 0, sizeof p);
+    p.cols = cols; p.rows = rows; p.M = j.stride;
+    p.H = j.d_H; p.P = j.d_P; p.top = j.d_top; p.left = j.d_left; p.right = j.d_right;
+    p.mm = sc->match - 2 * sc->gap; p.xm = sc->mismatch - 2 * sc->gap; p.ngap = -sc->gap;
+    p.edge = c->d_edge; p.tag_base = c->epoch << 20;
+    p.result_key = j.d_keys; p.abort_flag = (unsigned int*)(c->d_key + 1);
+    p.nstrips = (int)S;
+    p.debug_flags = (int)c->opt_debug;
+    p.dbg = (unsigned long long*)(uintptr_t)c->opt_dbg_ptr;
+    p.npairs = (int)j.npairs; p.store_hp = j.d_H ? 1 : 0;
+    p.a_pstride = j.a_pstride; p.b_pstride = j.b_pstride; p.hp_pstride = j.hp_pstride;
+    p.edge_pstride = S * (rows + 1);
+    const unsigned char* ua = (const unsigned char*)j.d_a;
+    const unsigned char* ub = (const unsigned char*)j.d_b;
+    if (systolic) {
+        const int NS = (int)c->opt_strips_per_group, NC = (int)c->opt_consumers;
+        // padded copies of b per problem: [front | b | tail]; front covers the fast producers' phi (< strips) + 63 lanes
+        const int64_t bfront = ((S + 64 + 127) / 128) * 128;
+        const int64_t per = ((rows + bfront + 512 + 15) / 16) * 16;
+        const size_t ncb = (size_t)per * (size_t)j.npairs;
+        if (ncb > c->cb_cap) {
             HIP_TRY(hipStreamSynchronize(stream));
-            if (c->d_edge) HIP_TRY(hipFree(c->d_edge));
-            c->d_edge = nullptr; c->edge_cap = 0;
-            if (hipMalloc((void**)&c->d_edge, need * 8) != hipSuccess) { set_err("workspace allocation of %zu bytes failed", need * 8); return SW_ENOMEM; }
-            c->edge_cap = need;
-            HIP_TRY(hipMemsetAsync(c->d_edge, 0, need * 8, stream));
-            c->epoch = 0;
+            if (c->d_cb) HIP_TRY(hipFree(c->d_cb));
+            c->d_cb = nullptr; c->cb_cap = 0;
+            if (hipMalloc((void**)&c->d_cb, ncb * 3 + 16) != hipSuccess) { set_err("workspace allocation failed"); return SW_ENOMEM; }
+            c->cb_cap = ncb;
         }
-        if (++c->epoch >= 4096) {  // 12-bit tag wrapped: stale tags could match again, wipe them
-            HIP_TRY(hipMemsetAsync(c->d_edge, 0, c->edge_cap * 8, stream));
-            c->epoch = 1;
-        }
-        swk::FillParams p;
-        p.cols = cols; p.rows = rows; p.M = M;
-        p.H = d_H; p.P = d_P; p.top = d_top;
-        p.mm = sc->match - 2 * sc->gap; p.xm = sc->mismatch - 2 * sc->gap; p.ngap = -sc->gap;
-        p.edge = c->d_edge; p.tag_base = c->epoch << 20;
-        p.result_key = c->d_key; p.abort_flag = (unsigned int*)(c->d_key + 1);
-        p.nstrips = (int)S;
-        p.debug_flags = (int)c->opt_debug;
-        p.dbg = (unsigned long long*)(uintptr_t)c->opt_dbg_ptr;
-        const unsigned char* ua = (const unsigned char*)d_a;
-        const unsigned char* ub = (const unsigned char*)d_b;
-        if (systolic) {
-            const int NS = (int)c->opt_strips_per_group, NC = (int)c->opt_consumers;
-            // padded copies of b: [front zeros | b | tail]; front covers the fast producers' phi (< strips) + 63 lanes
-            const int64_t bfront = ((S + 64 + 127) / 128) * 128;
-            const size_t ncb = (size_t)rows + (size_t)bfront + 512;
-            if (ncb > c->cb_cap) {
-                HIP_TRY(hipStreamSynchronize(stream));
-                if (c->d_cb) HIP_TRY(hipFree(c->d_cb));
-                c->d_cb = nullptr; c->cb_cap = 0;
-                if (hipMalloc((void**)&c->d_cb, ncb * 3 + 16) != hipSuccess) { set_err("workspace allocation failed"); return SW_ENOMEM; }
-                c->cb_cap = ncb;
-            }
-            unsigned short* d_cb16 = (unsigned short*)(c->d_cb + ((c->cb_cap + 15) / 16) * 16);
-            hipLaunchKernelGGL(swk::sw_pad_b, dim3((unsigned)((ncb + 255) / 256)), dim3(256), 0, stream, ub, rows, bfront, c->d_cb, d_cb16, (int64_t)ncb);
-            const bool fast = (d_top == nullptr) && (sc->mismatch <= 0) && !(c->opt_debug & 4);
-            p.phi_base = fast ? (int)S - 1 : -1;
-            p.bfront = (int)bfront;
-            p.bpad16 = d_cb16;
-            const int64_t ngroups = (S + NS - 1) / NS;
-            const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : (int64_t)c->num_cus;
-            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ngroups, maxb));
-            c->last_grid = grid; c->last_strips = S;
-            const int threads = 64 * (NS * (1 + NC) + 2);
-            const unsigned char* cbp = c->d_cb;
-            bool launched = false;
+        unsigned short* d_cb16 = (unsigned short*)(c->d_cb + ((c->cb_cap + 15) / 16) * 16);
+        hipLaunchKernelGGL(swk::sw_pad_b, dim3((unsigned)((per + 255) / 256), (unsigned)j.npairs), dim3(256), 0, stream, ub, rows, bfront,
+                           j.b_pstride, c->d_cb, d_cb16, per);
+        const bool fast = (j.d_top == nullptr) && (sc->mismatch <= 0) && !(c->opt_debug & 4);
+        p.phi_base = fast ? (int)S - 1 : -1;
+        p.bfront = (int)bfront;
+        p.bpad16 = d_cb16;
+        p.bpad_pstride = per;
+        const int64_t ngroups = ((S + NS - 1) / NS) * j.npairs;
+        const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : (int64_t)c->num_cus;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ngroups, maxb));
+        c->last_grid = grid; c->last_strips = S;
+        const int threads = 64 * (NS * (1 + NC) + 2);
+        const unsigned char* cbp = c->d_cb;
+        bool launched = false;
 #define SW_LAUNCH(ns, nc)                                                                                                        \
     if (!launched && NS == ns && NC == nc) {                                                                                      \
         launched = true;                                                                                                          \
-        if (h_elem_bytes == 4)                                                                                                    \
+        if (j.h_elem_bytes == 4)                                                                                                  \
             hipLaunchKernelGGL((swk::sw_systolic<int32_t, ns, nc>), dim3(grid), dim3(threads), 0, stream, ua, ub, cbp, p);       \
         else                                                                                                                      \
             hipLaunchKernelGGL((swk::sw_systolic<int64_t, ns, nc>), dim3(grid), dim3(threads), 0, stream, ua, ub, cbp, p);       \
     }
-            SW_LAUNCH(2, 2) SW_LAUNCH(2, 3) SW_LAUNCH(2, 4) SW_LAUNCH(1, 2) SW_LAUNCH(1, 4)
+        SW_LAUNCH(2, 2) SW_LAUNCH(2, 3) SW_LAUNCH(2, 4) SW_LAUNCH(1, 2) SW_LAUNCH(1, 4)
 #undef SW_LAUNCH
-            if (!launched) { set_err("unsupported strips_per_group/consumers combination %d/%d", NS, NC); return SW_EINVAL; }
-        } else {
-            const int wpb = (int)c->opt_waves_per_block;
-            const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : 2ll * c->num_cus;
-            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + wpb - 1) / wpb, maxb));
-            c->last_grid = grid; c->last_strips = S;
-            if (h_elem_bytes == 4)
-                hipLaunchKernelGGL((swk::sw_strip_scan<int32_t, 16>), dim3(grid), dim3(64 * wpb), 0, stream, ua, ub, p);
-            else
-                hipLaunchKernelGGL((swk::sw_strip_scan<int64_t, 16>), dim3(grid), dim3(64 * wpb), 0, stream, ua, ub, p);
-        }
+        if (!launched) { set_err("unsupported strips_per_group/consumers combination %d/%d", NS, NC); return SW_EINVAL; }
+    } else {
+        const int wpb = (int)c->opt_waves_per_block;
+        const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : 2ll * c->num_cus;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + wpb - 1) / wpb, maxb));
+        c->last_grid = grid; c->last_strips = S;
+        if (j.h_elem_bytes == 4)
+            hipLaunchKernelGGL((swk::sw_strip_scan<int32_t, 16>), dim3(grid), dim3(64 * wpb), 0, stream, ua, ub, p);
+        else
+            hipLaunchKernelGGL((swk::sw_strip_scan<int64_t, 16>), dim3(grid), dim3(64 * wpb), 0, stream, ua, ub, p);
+    }
+    HIP_TRY(hipGetLastError());
+    return SW_OK;
+}
+
+int sw_fill_tile_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
+                        void* d_H, int h_elem_bytes, int32_t* d_P, int64_t row_stride, const int32_t* d_top,
+                        const int32_t* d_left, int32_t* d_right, sw_result* d_result, void* stream_) {
+    static const sw_scores kDefault = {3, -3, -2};  // serial_smithW.c:59-61
+    const sw_scores* sc = scores ? scores : &kDefault;
+    if (!c || !d_H || !d_P || !d_result || (h_elem_bytes != 4 && h_elem_bytes != 8) || row_stride < cols + 1) {
+        set_err("sw_fill_tile_device: bad argument");
+        return SW_EINVAL;
+    }
+    if (int rc = check_dims(cols, rows, sc)) return rc;
+    if ((cols > 0 && !d_a) || (rows > 0 && !d_b)) { set_err("sw_fill_tile_device: NULL sequence"); return SW_EINVAL; }
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream));
+    if (cols == 0 || rows == 0) {
+        // no interior cell: H (= halo row / zero column) and P are all boundary
+        if (row_stride != cols + 1 || d_left || d_right) { set_err("empty tiles are not supported"); return SW_EINVAL; }
+        const int64_t M = cols + 1;
+        HIP_TRY(hipMemsetAsync(d_H, 0, (size_t)(M * (rows + 1)) * h_elem_bytes, stream));
+        HIP_TRY(hipMemsetAsync(d_P, 0, (size_t)(M * (rows + 1)) * 4, stream));
+        if (d_top && h_elem_bytes == 4) HIP_TRY(hipMemcpyAsync(d_H, d_top, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
+        if (d_top && h_elem_bytes == 8) { set_err("top halo with an empty int64 band is unsupported"); return SW_EINVAL; }
+    } else {
+        FillJob j = {d_a, cols, d_b, rows, d_H, h_elem_bytes, d_P, row_stride, d_top, d_left, d_right, 1, 0, 0, 0, c->d_key};
+        if (int rc = launch_fill(c, sc, j, stream)) return rc;
+    }
+    hipLaunchKernelGGL(swk::sw_finalize, dim3(1), dim3(64), 0, stream, c->d_key, (const unsigned int*)(c->d_key + 1), d_result, 1);
+    HIP_TRY(hipGetLastError());
+    return SW_OK;
+}
+
+int sw_fill_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
+                   void* d_H, int h_elem_bytes, int32_t* d_P, const int32_t* d_top, sw_result* d_result, void* stream_) {
+    return sw_fill_tile_device(c, d_a, cols, d_b, rows, scores, d_H, h_elem_bytes, d_P, cols + 1, d_top, nullptr, nullptr, d_result, stream_);
+}
+
+// BASELINE config 5: npairs independent cols x rows problems; pair k reads a at d_a + k*a_stride, b at d_b + k*b_stride.
+// d_H / d_P may both be NULL (score-only: max_score exact, max_pos = first row of the 16-row block that holds it).
+int sw_batch_device(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t cols, const char* d_b, int64_t b_stride, int64_t rows,
+                    int64_t npairs, const sw_scores* scores, int32_t* d_H, int32_t* d_P, sw_result* d_results, void* stream_) {
+    static const sw_scores kDefault = {3, -3, -2};
+    const sw_scores* sc = scores ? scores : &kDefault;
+    if (!c || !d_a || !d_b || !d_results || npairs <= 0 || cols <= 0 || rows <= 0 || ((d_H == nullptr) != (d_P == nullptr)) ||
+        a_stride < cols || b_stride < rows) {
+        set_err("sw_batch_device: bad argument");
+        return SW_EINVAL;
+    }
+    if (c->opt_engine != 0) { set_err("sw_batch_device needs the systolic engine"); return SW_EINVAL; }
+    if (int rc = check_dims(cols, rows, sc)) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t chunk_max = 4096;   // pairs per launch: bounds the edge / padded-b workspace
+    if ((size_t)std::min(npairs, chunk_max) > c->keys_cap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c->d_keys) HIP_TRY(hipFree(c->d_keys));
+        c->keys_cap = (size_t)std::min(npairs, chunk_max);
+        if (hipMalloc((void**)&c->d_keys, c->keys_cap * 8) != hipSuccess) { c->d_keys = nullptr; c->keys_cap = 0; set_err("workspace allocation failed"); return SW_ENOMEM; }
+    }
+    HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream));
+    const int64_t cells = (cols + 1) * (rows + 1);
+    for (int64_t k0 = 0; k0 < npairs; k0 += chunk_max) {
+        const int64_t n = std::min(chunk_max, npairs - k0);
+        HIP_TRY(hipMemsetAsync(c->d_keys, 0, (size_t)n * 8, stream));
+        FillJob j = {d_a + k0 * a_stride, cols, d_b + k0 * b_stride, rows, d_H ? (void*)(d_H + k0 * cells) : nullptr, 4,
+                     d_P ? d_P + k0 * cells : nullptr, cols + 1, nullptr, nullptr, nullptr, n, a_stride, b_stride, cells, c->d_keys};
+        if (int rc = launch_fill(c, sc, j, stream)) return rc;
+        hipLaunchKernelGGL(swk::sw_finalize, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, c->d_keys,
+                           (const unsigned int*)(c->d_key + 1), d_results + k0, (int)n);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(swk::sw_finalize, dim3(1), dim3(64), 0, stream, c->d_key, (const unsigned int*)(c->d_key + 1), d_result);
-    HIP_TRY(hipGetLastError());
     return SW_OK;
 }
 

@@ -12,10 +12,15 @@ constexpr unsigned long long SW_KEY_IDX_MASK = (1ull << 40) - 1;
 constexpr int64_t SW_MAX_DIM = (1 << 20) - 1; // rows/cols limit: 20-bit row tags, 40-bit indices
 
 struct FillParams {
-    int64_t cols, rows, M;     // M = cols + 1 = row stride
+    int64_t cols, rows, M;     // M = row stride of H/P in elements (cols + 1 for a whole matrix)
     void* H;                   // HT[(rows+1)*M]
     int32_t* P;                // int32[(rows+1)*M]
     const int32_t* top;        // optional halo row (cols+1), NULL = zeros
+    const int32_t* left;       // systolic: optional halo column (rows+1 H values of the column left of the tile), NULL = zeros
+    int32_t* right;            // systolic: optional output, H of the tile's last column (rows+1)
+    int npairs;                // systolic: independent problems in this launch (batch), 1 otherwise
+    int store_hp;              // systolic: 0 = score-only (H/P are not written)
+    int64_t a_pstride, b_pstride, bpad_pstride, hp_pstride, edge_pstride;  // per-pair strides (elements)
     int32_t mm, xm, ngap;      // match-2*gap, mismatch-2*gap, -gap  (G-space constants)
     unsigned long long* edge;  // [nstrips][rows+1] {tag,value} granules
     unsigned int tag_base;     // epoch << 20
@@ -33,8 +38,8 @@ template <typename HT, int B>
 __global__ void sw_strip_scan(const unsigned char* a, const unsigned char* b, FillParams p);
 template <typename HT, int NS, int NC>
 __global__ void sw_systolic(const unsigned char* a, const unsigned char* b, const unsigned char* bpad, FillParams p);
-__global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, unsigned char* bpad, unsigned short* bpad16, int64_t n);
-__global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res);
+__global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, int64_t b_pstride, unsigned char* bpad, unsigned short* bpad16, int64_t per);
+__global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res, int n);
 __global__ void sw_traceback(int32_t* P, int64_t M, int64_t maxPos, int64_t* path, int64_t cap, sw_result* res);
 template <typename T> __global__ void sw_row_checksums(const T* X, int64_t m, unsigned long long* cs);
 

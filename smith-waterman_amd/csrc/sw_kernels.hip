@@ -262,12 +262,13 @@ template __global__ void sw_strip_scan<int32_t, 16>(const unsigned char*, const 
 template __global__ void sw_strip_scan<int64_t, 16>(const unsigned char*, const unsigned char*, FillParams);
 
 // ---- small kernels --------------------------------------------------------------------------
-__global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res) {
-    if (threadIdx.x | blockIdx.x) return;
-    const u64 k = *key;
-    res->max_score = (int64_t)(k >> 40);
-    res->max_pos = k ? (int64_t)(SW_KEY_IDX_MASK - (k & SW_KEY_IDX_MASK)) : 0;
-    res->path_len = *abort_flag ? -1 : 0;
+__global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 k = key[i];
+    res[i].max_score = (int64_t)(k >> 40);
+    res[i].max_pos = k ? (int64_t)(SW_KEY_IDX_MASK - (k & SW_KEY_IDX_MASK)) : 0;
+    res[i].path_len = *abort_flag ? -1 : 0;
 }
 
 // backtrack(), serial_smithW.c:262-277: one lane walks P from maxPos and negates the path.

@@ -434,8 +434,7 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
 
 template <typename HT, int NS, int NC>
 __global__ void __launch_bounds__(64 * (NS * (1 + NC) + 2))
-sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __restrict__ seq_b,
-            const unsigned char* __restrict__ bpad, FillParams p) {
+sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsigned char* bpad, FillParams p) {
     __shared__ SysLds<NS> lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -448,7 +447,20 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
     const int phib = p.phi_base;
     auto u_total = [&](int s) { return (rows + SY_W + phi_of(s, phib) + SY_U - 1) / SY_U * SY_U; };  // local steps 1..u_total
 
-    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const unsigned char* const seq_a0 = seq_a; const unsigned char* const seq_b0 = seq_b; const unsigned char* const bpad0 = bpad;
+    const FillParams p0 = p;
+    for (int64_t gidx = blockIdx.x; gidx < (int64_t)ngroups * p0.npairs; gidx += gridDim.x) {
+        const int grp = (int)(gidx % ngroups);
+        const int64_t pair = gidx / ngroups;
+        // per-problem views (batch of independent pairs: BASELINE config 5)
+        seq_a = seq_a0 + pair * p0.a_pstride;
+        seq_b = seq_b0 + pair * p0.b_pstride;
+        bpad = bpad0 + pair * p0.bpad_pstride;
+        p.bpad16 = p0.bpad16 + pair * p0.bpad_pstride;
+        p.edge = p0.edge + pair * p0.edge_pstride;
+        p.result_key = p0.result_key + pair;
+        p.H = p0.H ? (void*)((char*)p0.H + pair * p0.hp_pstride * (int64_t)sizeof(HT)) : nullptr;
+        p.P = p0.P ? p0.P + pair * p0.hp_pstride : nullptr;
         if (threadIdx.x < NS) lds.prod_u[threadIdx.x] = 0;
         if (threadIdx.x < NS * 4) lds.cons_blk[threadIdx.x / 4][threadIdx.x % 4] = ((int)(threadIdx.x % 4) < NC) ? -1 : 0x7fffffff;
         if (threadIdx.x == 0) { lds.halo_ready = 1; lds.exp_done = 0; lds.never = 0x7fffffff; }
@@ -473,7 +485,7 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                 const int phi = phi_of(s, phib);
                 const int UT = u_total(s);
                 const u32 j = (u32)s * SY_W + (u32)lane;
-                const bool jvalid = (int64_t)j < M;
+                const bool jvalid = (int64_t)j <= p.cols;
                 const u32 a_l = (lane >= 1 && jvalid) ? (u32)seq_a[j - 1] : (u32)SY_ASENT;
                 const u32 G0v = jvalid ? (u32)((p.top ? p.top[j] : 0) + ngap * (int)j) : 0u;  // row 0 in G-space
                 const u32 mm_v = (u32)mm, xm_v = (u32)xm, ngap_v = (u32)ngap;
@@ -597,8 +609,13 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
             } else if (ls < nact) {
                 const int phi = phi_of(s, phib);
                 const u32 j = (u32)s * SY_W + (u32)lane;
-                const bool jvalid = (int64_t)j < M;
-                const bool store_ok = jvalid && (lane >= 1 || s == 0) && !(p.debug_flags & 1);
+                const bool jvalid = (int64_t)j <= p.cols;
+                // lane 0 of strip 0 is the tile's own column 0 only for a whole matrix (left == NULL)
+                const bool cell_ok = jvalid && (lane >= 1 || (s == 0 && p.left == nullptr));
+                const bool store_ok = cell_ok && p.store_hp && !(p.debug_flags & 1);
+                const bool last_strip = (s + 1 == p.nstrips);
+                const int lc = (int)p.cols - s * SY_W;          // lane of the tile's last column (in the last strip)
+                const bool right_lane = last_strip && p.right != nullptr && lane == lc;
                 const u32 voffH = store_ok ? j * (u32)sizeof(HT) : SY_OOB;
                 const u32 voffP = store_ok ? j * 4u : SY_OOB;
                 const int a_l = (lane >= 1 && jvalid) ? (int)seq_a[j - 1] : SY_ASENT;
@@ -606,10 +623,11 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                 const int G0v = jvalid ? (p.top ? p.top[j] : 0) + cz : 0;
                 HT* H = (HT*)p.H;
                 int32_t* P = p.P;
-                if (ci == 0 && store_ok) {  // row 0: the halo row itself
+                if (ci == 0 && store_ok) {  // row 0: the halo row itself (P of a row owned by the tile above is left alone)
                     H[j] = (HT)(p.top ? p.top[j] : 0);
-                    P[j] = 0;
+                    if (!p.top) P[j] = 0;
                 }
+                if (ci == 0 && right_lane) p.right[0] = p.top ? p.top[j] : 0;
                 int bestv = 0, bestblk = 0;   // arg-max: best value and the first of MY blocks that reached it
                 const u32 a_lu = (u32)a_l, mm_v = (u32)mm, xm_v = (u32)xm, ngap_v = (u32)ngap;
                 const int nblk = (rows + SY_U - 1) / SY_U;
@@ -650,11 +668,13 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                             __builtin_amdgcn_raw_buffer_store_b32((int)h, rH, voffH, (int)(rowH * (u32)k), 0);
                         }
                         __builtin_amdgcn_raw_buffer_store_b32((int)pr, rP, voffP, (int)(rowP * (u32)k), 0);
+                        if (right_lane) p.right[r0 + k] = (int)h;   // the tile's right edge column, for the next tile of this band
                     };
                     u32 blkmax = 0;
                     if (nb == SY_U) {
                         const uint4 w = *reinterpret_cast<const uint4*>(seq_b + (r0 - 1));  // this block's 16 row characters
-                        const u32 bw[4] = {w.x, w.y, w.z, w.w};
+                        const u32 bw[4] = {(u32)__builtin_amdgcn_readfirstlane((int)w.x), (u32)__builtin_amdgcn_readfirstlane((int)w.y),
+                                           (u32)__builtin_amdgcn_readfirstlane((int)w.z), (u32)__builtin_amdgcn_readfirstlane((int)w.w)};
                         u32 z = (u32)(cz + ngap * (r0 - 1));
                         sfor<0, 4>([&](auto Q) {
                             constexpr int k = Q.value * 4;
@@ -680,12 +700,17 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
                     lds_store(&lds.cons_blk[ls][ci], q);
                 }
                 // arg-max: the lowest row of block `bestblk` holding bestv in my column (re-read what this wave stored)
-                if (store_ok && bestv > 0) {
-                    __builtin_amdgcn_s_waitcnt(0);  // my own stores have reached L2
-                    int bestrow = 0;
-                    for (int k = SY_U - 1; k >= 0; --k) {
-                        const int r = bestblk * SY_U + 1 + k;
-                        if (r <= rows && (int)__builtin_nontemporal_load(&H[(int64_t)r * M + j]) == bestv) bestrow = r;
+                if (cell_ok && !(p.debug_flags & 1) && bestv > 0) {
+                    int bestrow = bestblk * SY_U + 1;
+                    if (p.store_hp) {
+                        __builtin_amdgcn_s_waitcnt(0);  // my own stores have reached L2
+                        for (int k = SY_U - 1; k >= 0; --k) {
+                            const int r = bestblk * SY_U + 1 + k;
+                            if (r <= rows && (int)__builtin_nontemporal_load(&H[(int64_t)r * M + j]) == bestv) bestrow = r;
+                        }
+                    } else {
+                        // score-only: recompute the 16 rows of that block from the ring?  It is long gone: report the
+                        // block's first row (max_score is exact; max_pos is exact only with store_hp)
                     }
                     const u64 idx = (u64)bestrow * (u64)M + (u64)j;
                     atomicMax(p.result_key, ((u64)(u32)bestv << 40) | (SW_KEY_IDX_MASK - idx));
@@ -707,7 +732,7 @@ sw_systolic(const unsigned char* __restrict__ seq_a, const unsigned char* __rest
             auto edge_val = [&](int r, bool& ok) -> u32 {  // G of (row r, column 63*s0): the halo of strip s0
                 ok = true;
                 if (r <= 0) return (r == 0) ? halo_row0 : (u32)(ngap * (r + s0 * SY_W));  // above the matrix: H == 0 floor
-                if (s0 == 0) return (u32)(ngap * r);                                        // column 0: H == 0
+                if (s0 == 0) return (u32)(ngap * r + (p.left ? p.left[r] : 0));           // column 0: H == 0, or the tile's left halo column
                 const u64 gr = __hip_atomic_load((gu64*)(p.edge + (int64_t)(s0 - 1) * estride + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = (gr >> 32) == (tag_base | (u64)r);
                 return (u32)gr;
@@ -786,13 +811,15 @@ SW_INST(1, 4)
 // bpad[front + i] = b[i] (bytes, zero padded) and bpad16[front + i] = b[i] (16-bit, padded with the
 // never-matching 0x100): producer lane l reads b[u-phi-l-1] for steps that reach phi+63 rows above and
 // ~200 rows below the matrix (those cells are never stored).
-__global__ void sw_pad_b(const unsigned char* __restrict__ b, int64_t rows, int64_t front, unsigned char* __restrict__ bpad,
-                         unsigned short* __restrict__ bpad16, int64_t n) {
+__global__ void sw_pad_b(const unsigned char* __restrict__ b, int64_t rows, int64_t front, int64_t b_pstride,
+                         unsigned char* __restrict__ bpad, unsigned short* __restrict__ bpad16, int64_t per) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
+    const int64_t pair = blockIdx.y;  // batch: one padded copy per problem
+    if (i < per) {
         const bool in = (i >= front && i - front < rows);
-        bpad[i] = in ? b[i - front] : (unsigned char)0;
-        bpad16[i] = in ? (unsigned short)b[i - front] : (unsigned short)0x100;  // 0x100 never equals a character
+        const unsigned char ch = in ? b[pair * b_pstride + i - front] : (unsigned char)0;
+        bpad[pair * per + i] = ch;
+        bpad16[pair * per + i] = in ? (unsigned short)ch : (unsigned short)0x100;  // 0x100 never equals a character
     }
 }
 
