@@ -54,6 +54,58 @@ def cpu_baseline(cols, rows):
     return out
 
 
+def alt_modes(args, sw, eng, torch, dist, rank, world, local):
+    """--mode bands / batch: same timing contract (warm-up, K timed steps, barrier + synchronize, max over ranks)."""
+    import numpy as np
+    cols, rows = args.cols, args.rows
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.mode == "batch":
+        npairs = args.pairs
+        A = np.stack([sw.generate(cols, rows, 1 + rank * npairs + k)[0] for k in range(npairs)])
+        B = np.stack([sw.generate(cols, rows, 1 + rank * npairs + k)[1] for k in range(npairs)])
+        step = lambda: eng.batch(A, B, store=args.store)   # includes the H2D of the sequences (a few MB)
+        cells = npairs * cols * rows
+        what = f"{npairs} independent {cols}x{rows} pairs per GPU in one launch ({'H/P stored' if args.store else 'score-only'})"
+    else:
+        multi = importlib.import_module("smith-waterman_amd.multi")
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29613")
+            dist.init_process_group("gloo", rank=0, world_size=1)
+        a, _ = sw.generate(cols, rows, 1)
+        bb = np.concatenate([sw.generate(cols, rows, 1 + r)[1] for r in range(world)])   # world*rows rows in total
+        pipe = multi.BandPipeline(dist, rank, world, a, bb, nchunks=args.chunks, make_tiles=lambda *x: multi.GpuTiles(eng, *x))
+        step = pipe.fill
+        cells = cols * rows * world
+        what = f"ONE {cols} x {rows * world} matrix as {world} row bands x {len(pipe.chunks)} column chunks, p2p halo rows"
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=f"cuda:{local}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        tot = cells * (world if args.mode == "batch" else 1)
+        print(json.dumps({"metric": "GCUPS (DP cell updates/s)", "value": args.steps * tot / dt / 1e9, "unit": "GCUPS", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                          "config": {"workload": what, "mode": args.mode}}), flush=True)
+    eng.close()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +115,13 @@ def main():
     ap.add_argument("--rows", type=int, default=16384)
     ap.add_argument("--h64", action="store_true", help="int64 H (BASELINE config 3 element type)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--mode", default="pair", choices=["pair", "bands", "batch"],
+                    help="pair: one independent cols x rows pair per GPU (default, the BASELINE metric); "
+                         "bands: ONE (gpus*rows) x cols matrix as row bands over the GPUs with p2p halo rows; "
+                         "batch: --pairs independent pairs per GPU in one launch (BASELINE config 5)")
+    ap.add_argument("--chunks", type=int, default=8, help="bands mode: column chunks per band")
+    ap.add_argument("--pairs", type=int, default=512, help="batch mode: pairs per GPU")
+    ap.add_argument("--store", action="store_true", help="batch mode: also write H/P of every pair")
     ap.add_argument("--engine", type=int, default=0, help="0 systolic (default), 1 strip_scan")
     ap.add_argument("--ns", type=int, default=0, help="systolic: strips per workgroup")
     ap.add_argument("--nc", type=int, default=0, help="systolic: consumer waves per strip")
@@ -96,6 +155,8 @@ def main():
         eng.set_option("max_blocks", args.max_blocks)
 
     cols, rows = args.cols, args.rows
+    if args.mode != "pair":
+        return alt_modes(args, sw, eng, torch, dist, rank, world, local)
     a, b = sw.generate(cols, rows, 1 + rank)          # reference generator; rank r uses seed 1+r
     d_a, _ = eng.to_device(a)
     d_b, _ = eng.to_device(b)
