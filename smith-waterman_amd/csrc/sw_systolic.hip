@@ -747,12 +747,32 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                     int base = imp;
                     u32 vals[4];
                     bool oks[4];
+                    if (s0 > 0) {
+                        // branch-free: four granule loads in flight at once (clamped addresses), validity by selects
+                        u64 gr[4];
+                        const u64* eb = p.edge + (int64_t)(s0 - 1) * estride;
 #pragma unroll
-                    for (int b4 = 0; b4 < 4; ++b4) {   // all four loads in flight before anything looks at them
-                        const int r = imp + b4 * 64 + lane;
-                        oks[b4] = false;
-                        vals[b4] = 0;
-                        if (r < lim) vals[b4] = edge_val(r, oks[b4]);
+                        for (int b4 = 0; b4 < 4; ++b4) {
+                            const int r = imp + b4 * 64 + lane;
+                            gr[b4] = __hip_atomic_load((gu64*)(eb + min(max(r, 1), rows)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                        for (int b4 = 0; b4 < 4; ++b4) {
+                            const int r = imp + b4 * 64 + lane;
+                            const bool tag_ok = (gr[b4] >> 32) == (tag_base | (u64)(u32)max(r, 1));
+                            const u32 above = (r == 0) ? halo_row0 : (u32)(ngap * (r + s0 * SY_W));   // rows <= 0: H == 0 floor / halo row
+                            vals[b4] = (r <= 0) ? above : (u32)gr[b4];
+                            oks[b4] = (r < lim) && (r <= 0 || tag_ok);
+                        }
+                    } else {
+#pragma unroll
+                        for (int b4 = 0; b4 < 4; ++b4) {
+                            const int r = imp + b4 * 64 + lane;
+                            bool ok = false;
+                            vals[b4] = 0;
+                            if (r < lim) vals[b4] = edge_val(r, ok);
+                            oks[b4] = ok;
+                        }
                     }
 #pragma unroll
                     for (int b4 = 0; b4 < 4; ++b4) {
@@ -766,6 +786,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                     }
                     if (base > imp) {
                         asm volatile("" ::: "memory");  // LDS executes a wave's ops in order: data before counter
+                        if (p.dbg && lane == 0 && imp <= rows / 2 && base > rows / 2) p.dbg[2 * p.nstrips + 8 + 2 * grp] = __builtin_amdgcn_s_memrealtime();
                         imp = base;
                         lds_store(&lds.halo_ready, imp + phi0);  // local steps < imp+phi0 are in halo[]
                         progressed = true;
@@ -784,6 +805,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                             __hip_atomic_store((gu64*)(p.edge + (int64_t)slast * estride + r), ((tag_base | (u64)r) << 32) | (u64)v,
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
+                        if (p.dbg && lane == 0 && exp <= rows / 2 && exp + n > rows / 2) p.dbg[2 * p.nstrips + 9 + 2 * grp] = __builtin_amdgcn_s_memrealtime();
                         exp += n;
                         lds_store(&lds.exp_done, exp - 1);
                         progressed = true;
