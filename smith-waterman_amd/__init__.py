@@ -164,7 +164,10 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().sw_destroy(self._h)
+            try:
+                lib().sw_destroy(self._h)
+            except Exception:  # interpreter shutdown: module globals are already gone
+                pass
             self._h = None
 
     __del__ = close

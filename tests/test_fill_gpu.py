@@ -155,3 +155,28 @@ def test_full_size_16384_streaming_checksums(engine, oracle, swamd):
     assert np.array_equal(out.H[-1].cpu().numpy(), st["bottom"])
     n = engine.traceback(out, want_path=False)
     assert 16384 < n < 3 * 16384
+
+
+@pytest.mark.skipif(not os.environ.get("SW_BIG"), reason="BASELINE config 3 at full size: set SW_BIG=1 (needs ~55 GB of HBM, ~40 s of host time)")
+def test_config3_65536_int64_streaming_checksums(engine, oracle, swamd, engine_kind):
+    """BASELINE config 3 (65536 x 65536, int64 H + int32 P, resident in HBM): per-row checksums, arg-max, bottom row
+    against the streaming oracle; every int64 H must be the sign extension of its int32 value."""
+    import torch
+    if engine_kind != 0:
+        pytest.skip("systolic engine only")
+    n = 65536
+    a, b = swamd.generate(n, n, 1)
+    d_a, _ = engine.to_device(a)
+    d_b, _ = engine.to_device(b)
+    out = engine.alloc(n, n, torch.int64)
+    engine.fill_into(out, d_a, d_b)
+    engine.synchronize()
+    r = out.result()
+    csH, csP = engine.row_checksums(out.H), engine.row_checksums(out.P)
+    bottom = out.H[-1].cpu().numpy()
+    st = oracle.fill_streaming(a, b)
+    assert r["max_pos"] == st["max_pos"] and r["max_score"] == st["max_score"]
+    assert np.array_equal(csH, st["csH"]) and np.array_equal(csP, st["csP"])
+    assert np.array_equal(bottom.astype(np.int32), st["bottom"]) and bottom.dtype == np.int64
+    plen = engine.traceback(out, want_path=False)
+    assert n < plen < 3 * n
