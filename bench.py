@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--engine", type=int, default=0, help="0 systolic (default), 1 strip_scan")
     ap.add_argument("--ns", type=int, default=0, help="systolic: strips per workgroup")
     ap.add_argument("--nc", type=int, default=0, help="systolic: consumer waves per strip")
+    ap.add_argument("--pace", type=int, default=-1, help="systolic: strip-0 pacing in ps per row (0 = off, -1 = library default)")
     ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--wpb", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
@@ -143,6 +144,8 @@ def main():
     sw = importlib.import_module("smith-waterman_amd")
     eng = sw.Engine(local)
     eng.set_option("engine", args.engine)
+    if args.pace >= 0:
+        eng.set_option("pace_ps", args.pace)
     if args.ns:
         eng.set_option("strips_per_group", args.ns)
     if args.nc:

@@ -20,7 +20,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswhip.so")
+LIB_PATH = os.environ.get("SWHIP_LIBRARY") or os.path.join(_HERE, "libswhip.so")  # override: A/B builds of the kernels
 
 NONE, UP, LEFT, DIAGONAL, PATH = 0, 1, 2, 3, -1
 DEFAULT_SCORES = (3, -3, -2)  # serial_smithW.c:59-61

@@ -29,6 +29,7 @@ struct sw_ctx {
     unsigned char* d_cb = nullptr;      // systolic engine: zero-padded copy of b (sw_pad_b)
     size_t cb_cap = 0;
     int64_t opt_debug = 0;
+    int64_t opt_pace_ps = 0;            // systolic: pacing of strip 0 (ps per row; 0 = off)
     int64_t opt_dbg_ptr = 0;
     int64_t opt_engine = 0;             // 0 = systolic producer/consumer pipeline, 1 = strip_scan (row scan)
     int64_t opt_strips_per_group = 2;   // systolic: producer waves (strips) per workgroup
@@ -78,6 +79,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "strips_per_group")) { c->opt_strips_per_group = v ? v : 2; return SW_OK; }
     if (!strcmp(name, "consumers")) { c->opt_consumers = v ? v : 4; return SW_OK; }
     if (!strcmp(name, "debug_flags")) { c->opt_debug = v; return SW_OK; }
+    if (!strcmp(name, "pace_ps")) { c->opt_pace_ps = v; return SW_OK; }
     if (!strcmp(name, "debug_buf")) { c->opt_dbg_ptr = v; return SW_OK; }
     if (!strcmp(name, "engine")) {
         if (v != 0 && v != 1) { set_err("engine must be 0 (systolic) or 1 (strip_scan)"); return SW_EINVAL; }
@@ -158,6 +160,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
     p.result_key = j.d_keys; p.abort_flag = (unsigned int*)(c->d_key + 1);
     p.nstrips = (int)S;
     p.debug_flags = (int)c->opt_debug;
+    p.pace_ps = (int)c->opt_pace_ps;
     p.dbg = (unsigned long long*)(uintptr_t)c->opt_dbg_ptr;
     p.npairs = (int)j.npairs; p.store_hp = j.d_H ? 1 : 0;
     p.a_pstride = j.a_pstride; p.b_pstride = j.b_pstride; p.hp_pstride = j.hp_pstride;
@@ -200,7 +203,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         else                                                                                                                      \
             hipLaunchKernelGGL((swk::sw_systolic<int64_t, ns, nc>), dim3(grid), dim3(threads), 0, stream, ua, ub, cbp, p);       \
     }
-        SW_LAUNCH(2, 2) SW_LAUNCH(2, 3) SW_LAUNCH(2, 4) SW_LAUNCH(1, 2) SW_LAUNCH(1, 4)
+        SW_LAUNCH(2, 2) SW_LAUNCH(2, 3) SW_LAUNCH(2, 4) SW_LAUNCH(1, 2) SW_LAUNCH(1, 3) SW_LAUNCH(1, 4) SW_LAUNCH(1, 6) SW_LAUNCH(1, 8) SW_LAUNCH(2, 6) SW_LAUNCH(2, 5)
 #undef SW_LAUNCH
         if (!launched) { set_err("unsupported strips_per_group/consumers combination %d/%d", NS, NC); return SW_EINVAL; }
     } else {

@@ -260,6 +260,7 @@ __device__ __forceinline__ int phi_of(int s, int phi_base) { return phi_base >= 
     "s_cbranch_scc1 Lrd" #KB "_%=\n\t"                                                       \
     "s_sleep 1\n\t"                                                                          \
     "s_add_i32 s89, s89, 1\n\t"                                                              \
+    "s_add_i32 s95, s95, 1\n\t"                                                              \
     "s_cmp_lt_u32 s89, 0x1000000\n\t"                                                        \
     "s_cbranch_scc1 Lpoll" #KB "_%=\n\t"                                                     \
     "s_mov_b32 %[status], 1\n\t"                                                             \
@@ -271,12 +272,15 @@ __device__ __forceinline__ int phi_of(int s, int phi_base) { return phi_base >= 
 
 __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ngap_v, u32 wbase, u32 voff, u32 z0,
                                              const unsigned short* cbase, u32 hbase, int hoff4, u32 cnt_addr,
-                                             u32 cons_addr, u32 right_addr, u32 prog_addr, int UT, int k1, int k2, int kc, int kr, int hmask) {
+                                             u32 cons_addr, u32 right_addr, u32 prog_addr, int UT, int k1, int k2, int kc, int kr, int hmask,
+                                             int (&polls)[2]) {
     int status;
     asm volatile(
         "s_setprio 3\n\t"                          /* producers own the critical path: win VALU arbitration on their SIMD */
         "s_mov_b32 %[status], 0\n\t"
         "s_mov_b32 s84, 0\n\t"
+        "s_mov_b32 s94, 0\n\t"
+        "s_mov_b32 s95, 0\n\t"
         "s_mov_b32 s88, 1\n\t"
         "s_mov_b32 s90, 0\n\t"
         "s_and_b32 s91, %[hoff4], %[hmask]\n\t"   /* byte offset of this chunk's halo inside the halo source ring */
@@ -320,6 +324,7 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
         "Lbpw_%=:\n\t"
         "s_sleep 1\n\t"
         "s_add_i32 s89, s89, 1\n\t"
+        "s_add_i32 s94, s94, 1\n\t"
         "s_cmp_lt_u32 s89, 0x1000000\n\t"
         "s_cbranch_scc1 Lbp_%=\n\t"
         "s_mov_b32 %[status], 2\n\t"
@@ -350,11 +355,13 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
         "Lexit_%=:\n\t"
         "s_setprio 0\n\t"
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        : [status] "=&s"(status)
+        "s_mov_b32 %[nbp], s94\n\t"
+        "s_mov_b32 %[nhalo], s95\n\t"
+        : [status] "=&s"(status), [nbp] "=&s"(polls[0]), [nhalo] "=&s"(polls[1])
         : [a] "v"(a_l), [xm] "v"(xm_v), [mm] "v"(mm_v), [ngap] "v"(ngap_v), [wbase] "v"(wbase), [voff] "v"(voff), [z0] "v"(z0),
           [cbase] "s"(cbase), [hbase] "s"(hbase), [hoff4] "s"(hoff4), [cntaddr] "s"(cnt_addr), [consaddr] "s"(cons_addr),
           [rightaddr] "s"(right_addr), [progaddr] "s"(prog_addr), [ut] "s"(UT), [k1] "s"(k1), [k2] "s"(k2), [kc] "s"(kc), [kr] "s"(kr), [hmask] "s"(hmask)
-        : "vcc", "scc", "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
+        : "vcc", "scc", "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
           "v56", "v57", "v58", "v59", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
           "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91",
           "v92", "v93", "v94", "v95", "v96", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
@@ -432,6 +439,88 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
     return o;
 }
 
+// =================================================================================================
+// Consumer, whole 16-row block in ONE asm statement (int32 H, the common case).  hipcc's own code
+// around four consumer_rows4 statements and 32 buffer stores came to ~650 instructions per block
+// (SGPR spills through v_readlane, per-row branches, and an s_waitcnt vmcnt(0) for the row
+// characters that also waited for every outstanding H/P store); this is ~270.
+//   phase 1: z, H = g - z, store H (needs no characters: hides the scalar load of the 16 row characters)
+//   phase 2: per row s', diagonal candidate, P (serial_smithW.c:204-234), store P
+// literal temporaries: v[100:115] H of the 16 rows, v[116:119] s', v[120:123] diagonal candidates,
+// v[124:127] P; s[60:75] compare masks, s[76:79] the row characters, s80 row byte offset
+// =================================================================================================
+#ifndef CB_POLICY
+#define CB_POLICY " nt"   /* streaming stores: H and P are written once and never re-read by the fill (measured -18% at 16384^2) */
+#endif
+#define CB_H(K, G)                                                                            \
+    "v_add_u32 %[z], %[z], %[ngap]\n\t"                                                      \
+    "v_sub_u32 v" #K ", %[" G "], %[z]\n\t"                                                   \
+    "buffer_store_dword v" #K ", %[voff], %[rH], s80 offen" CB_POLICY "\n\t"                              \
+    "s_add_u32 s80, s80, %[stride]\n\t"
+#define CB_PRED(G, UP, DD, M1, M3)                                                            \
+    "v_cmp_eq_u32_e64 " M1 ", %[" UP "], %[" G "]\n\t"                                       \
+    "v_cmp_eq_u32_e64 " M3 ", " DD ", %[" G "]\n\t"
+#define CB_SEL(HK, PI, M1, M3)                                                                \
+    "v_cmp_eq_u32_e32 vcc, 0, " HK "\n\t"                                                    \
+    "v_cndmask_b32_e64 " PI ", 2, 1, " M1 "\n\t"                                             \
+    "v_cndmask_b32_e64 " PI ", " PI ", 3, " M3 "\n\t"                                        \
+    "v_cndmask_b32_e64 " PI ", " PI ", 0, vcc\n\t"                                           \
+    "buffer_store_dword " PI ", %[voff], %[rP], s80 offen" CB_POLICY "\n\t"                               \
+    "s_add_u32 s80, s80, %[stride]\n\t"
+#define CB_GROUP(CH, U, G0, G1, G2, G3, H0, H1, H2, H3)                                       \
+    "v_cmp_eq_u32_sdwa s[60:61], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_0\n\t"            \
+    "v_cmp_eq_u32_sdwa s[62:63], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_1\n\t"            \
+    "v_cmp_eq_u32_sdwa s[64:65], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_2\n\t"            \
+    "v_cmp_eq_u32_sdwa s[66:67], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_3\n\t"            \
+    "v_cndmask_b32_e64 v116, %[xm], %[mm], s[60:61]\n\t"                                     \
+    "v_cndmask_b32_e64 v117, %[xm], %[mm], s[62:63]\n\t"                                     \
+    "v_cndmask_b32_e64 v118, %[xm], %[mm], s[64:65]\n\t"                                     \
+    "v_cndmask_b32_e64 v119, %[xm], %[mm], s[66:67]\n\t"                                     \
+    "v_add_u32_dpp v120, %[" U "], v116 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"  \
+    "v_add_u32_dpp v121, %[" G0 "], v117 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+    "v_add_u32_dpp v122, %[" G1 "], v118 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+    "v_add_u32_dpp v123, %[" G2 "], v119 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+    CB_PRED(G0, U, "v120", "s[60:61]", "s[62:63]")                                            \
+    CB_PRED(G1, G0, "v121", "s[64:65]", "s[66:67]")                                           \
+    CB_SEL(H0, "v124", "s[60:61]", "s[62:63]")                                                \
+    CB_PRED(G2, G1, "v122", "s[68:69]", "s[70:71]")                                           \
+    CB_SEL(H1, "v125", "s[64:65]", "s[66:67]")                                                \
+    CB_PRED(G3, G2, "v123", "s[72:73]", "s[74:75]")                                           \
+    CB_SEL(H2, "v126", "s[68:69]", "s[70:71]")                                                \
+    CB_SEL(H3, "v127", "s[72:73]", "s[74:75]")
+typedef int sw_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void consumer_block16(const u32 (&g)[SY_U + 1], u32& z, u32& blkmax, u32 a_l, u32 mm_v, u32 xm_v, u32 ngap_v,
+                                                 u32 voff, sw_i32x4 rH, sw_i32x4 rP, u32 stride, const unsigned char* chars) {
+    asm volatile(
+        "s_load_dwordx4 s[76:79], %[cptr], 0x0\n\t"
+        "s_mov_b32 s80, 0\n\t"
+        CB_H(100, "g1") CB_H(101, "g2") CB_H(102, "g3") CB_H(103, "g4") CB_H(104, "g5") CB_H(105, "g6") CB_H(106, "g7") CB_H(107, "g8")
+        CB_H(108, "g9") CB_H(109, "g10") CB_H(110, "g11") CB_H(111, "g12") CB_H(112, "g13") CB_H(113, "g14") CB_H(114, "g15") CB_H(115, "g16")
+        "v_max3_i32 %[bm], %[bm], v100, v101\n\t"
+        "v_max3_i32 v116, v102, v103, v104\n\t"
+        "v_max3_i32 v117, v105, v106, v107\n\t"
+        "v_max3_i32 v118, v108, v109, v110\n\t"
+        "v_max3_i32 v119, v111, v112, v113\n\t"
+        "v_max3_i32 %[bm], %[bm], v114, v115\n\t"
+        "v_max3_i32 v116, v116, v117, v118\n\t"
+        "v_max3_i32 %[bm], %[bm], v116, v119\n\t"
+        "s_mov_b32 s80, 0\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        CB_GROUP("s76", "g0", "g1", "g2", "g3", "g4", "v100", "v101", "v102", "v103")
+        CB_GROUP("s77", "g4", "g5", "g6", "g7", "g8", "v104", "v105", "v106", "v107")
+        CB_GROUP("s78", "g8", "g9", "g10", "g11", "g12", "v108", "v109", "v110", "v111")
+        CB_GROUP("s79", "g12", "g13", "g14", "g15", "g16", "v112", "v113", "v114", "v115")
+        : [z] "+v"(z), [bm] "+v"(blkmax)
+        : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]), [g7] "v"(g[7]),
+          [g8] "v"(g[8]), [g9] "v"(g[9]), [g10] "v"(g[10]), [g11] "v"(g[11]), [g12] "v"(g[12]), [g13] "v"(g[13]), [g14] "v"(g[14]),
+          [g15] "v"(g[15]), [g16] "v"(g[16]), [a] "v"(a_l), [mm] "v"(mm_v), [xm] "v"(xm_v), [ngap] "v"(ngap_v), [voff] "v"(voff),
+          [rH] "s"(rH), [rP] "s"(rP), [stride] "s"(stride), [cptr] "s"(chars)
+        : "vcc", "scc", "memory", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
+          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",
+          "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
+          "v124", "v125", "v126", "v127");
+}
+
 template <typename HT, int NS, int NC>
 __global__ void __launch_bounds__(64 * (NS * (1 + NC) + 2))
 sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsigned char* bpad, FillParams p) {
@@ -472,11 +561,14 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
         // Role of each wave.  Waves are dealt to the four SIMDs cyclically, so waves w, w+4, w+8 share a
         // SIMD: with NS == 2 the two mostly-sleeping helper waves take slots 4 and 5, i.e. the SIMDs of the
         // two producers (waves 0 and 1), and every consumer wave shares at most with one producer.
+        // With NS == 1 the helpers take waves 4 and 8 (the producer's SIMD), so no consumer shares with it.
         constexpr int NWAVES = NS * (1 + NC) + 2;
+        static_assert(NWAVES <= 16 && NC <= 8, "at most 1024 threads; four counter slots shared by up to two consumers each");
         constexpr bool helpers_mid = (NS == 2 && NWAVES > 6);
-        const int h_imp = helpers_mid ? 4 : NWAVES - 2, h_exp = helpers_mid ? 5 : NWAVES - 1;
+        constexpr bool helpers_s0 = (NS == 1 && NWAVES >= 9);
+        const int h_imp = (helpers_mid || helpers_s0) ? 4 : NWAVES - 2, h_exp = helpers_mid ? 5 : helpers_s0 ? 8 : NWAVES - 1;
         const bool is_helper = (wave == h_imp || wave == h_exp);
-        const int cw = helpers_mid ? (wave < 4 ? wave - NS : wave - NS - 2) : wave - NS;  // consumer ordinal 0..NS*NC-1
+        const int cw = wave - NS - (wave > h_imp ? 1 : 0) - (wave > h_exp ? 1 : 0);  // consumer ordinal 0..NS*NC-1
         if (wave < NS) {
             // ================================ producer ================================
             const int ls = wave, s = s0 + ls;
@@ -524,10 +616,16 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                     // my lane-63 entries of steps <= uc-193 get overwritten: the right-hand producer read them at its
                     // local step (mine - 64); the exporter counts ROWS (= my step - 63 - phi)
                     const int kr = has_right ? -(SY_R + 1) + 16 : -SY_R - phi;
+                    int polls[2];
                     const int st = producer_fast(a_l, xm_v, mm_v, ngap_v, wbase, voff, z0, p.bpad16, hbase, hoff * 4, cnt_addr,
                                                  (u32)(size_t)&lds.cons_blk[ls][0], (u32)(size_t)right_cnt, (u32)(size_t)&lds.prod_u[ls],
-                                                 UT, k1, k2, kc, kr, hmask * 4 + 3);
-                    if (p.dbg && lane == 0) p.dbg[2 * s + 1] = __builtin_amdgcn_s_memrealtime();
+                                                 UT, k1, k2, kc, kr, hmask * 4 + 3, polls);
+                    if (p.dbg && lane == 0) {
+                        p.dbg[2 * s + 1] = __builtin_amdgcn_s_memrealtime();
+                        // slow-path polls of this strip: ring back-pressure / halo not there yet (after the strip times and hop stamps)
+                        p.dbg[4 * p.nstrips + 16 + 2 * s] = (u64)polls[0];
+                        p.dbg[4 * p.nstrips + 17 + 2 * s] = (u64)polls[1];
+                    }
                     if (st) {
                         __hip_atomic_store((gu32*)p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         return;
@@ -605,7 +703,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
             // ================================ consumer ================================
             const int ls = cw % NS, ci = cw / NS, s = s0 + ls;
             if (ls < nact && (p.debug_flags & 2)) {
-                lds_store(&lds.cons_blk[ls][ci], 1 << 24);  // timing experiment: producer alone
+                lds_store(&lds.cons_blk[ls][ci & 3], 1 << 24);  // timing experiment: producer alone
             } else if (ls < nact) {
                 const int phi = phi_of(s, phib);
                 const u32 j = (u32)s * SY_W + (u32)lane;
@@ -615,7 +713,8 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 const bool store_ok = cell_ok && p.store_hp && !(p.debug_flags & 1);
                 const bool last_strip = (s + 1 == p.nstrips);
                 const int lc = (int)p.cols - s * SY_W;          // lane of the tile's last column (in the last strip)
-                const bool right_lane = last_strip && p.right != nullptr && lane == lc;
+                const bool right_strip = last_strip && p.right != nullptr;   // this strip also returns the tile's right edge column
+                const bool right_lane = right_strip && lane == lc;
                 const u32 voffH = store_ok ? j * (u32)sizeof(HT) : SY_OOB;
                 const u32 voffP = store_ok ? j * 4u : SY_OOB;
                 const int a_l = (lane >= 1 && jvalid) ? (int)seq_a[j - 1] : SY_ASENT;
@@ -634,6 +733,12 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 const u32* myring = (const u32*)&lds.ring[ls][lane * SY_LSTR];
                 int snap_prod = 0;
                 Spin spin;
+                // progress counters: four slots per strip; consumers ci and ci+4 share slot ci%4 (NC > 4)
+                const int slot = ci & 3;
+                const int partner = (NC > 4) ? ((ci >= 4) ? ci - 4 : (ci + 4 < NC ? ci + 4 : -1)) : -1;
+                // every load issued so far (a, top) has landed before the loop: inside it, a wait for one of them
+                // would be a vmcnt(0), i.e. a wait for all the H/P stores of the previous block as well
+                __builtin_amdgcn_s_waitcnt(0x0F70);
                 for (int q = ci; q < nblk; q += NC) {
                     const int r0 = q * SY_U + 1;
                     const int nb = min(SY_U, rows - r0 + 1);
@@ -671,7 +776,14 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                         if (right_lane) p.right[r0 + k] = (int)h;   // the tile's right edge column, for the next tile of this band
                     };
                     u32 blkmax = 0;
-                    if (nb == SY_U) {
+                    if (sizeof(HT) == 4 && nb == SY_U && !right_strip) {
+                        // the common case: whole block in one asm statement
+                        u32 z = (u32)(cz + ngap * (r0 - 1));
+                        const uint64_t bH = (uint64_t)(uintptr_t)((int32_t*)H + (int64_t)r0 * M), bP = (uint64_t)(uintptr_t)(P + (int64_t)r0 * M);
+                        const sw_i32x4 dH = {(int)(u32)bH, (int)(u32)(bH >> 32), 0x7FFFFF00, 0x00020000};
+                        const sw_i32x4 dP = {(int)(u32)bP, (int)(u32)(bP >> 32), 0x7FFFFF00, 0x00020000};
+                        consumer_block16(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, dH, dP, rowP, seq_b + (r0 - 1));
+                    } else if (nb == SY_U) {
                         const uint4 w = *reinterpret_cast<const uint4*>(seq_b + (r0 - 1));  // this block's 16 row characters
                         const u32 bw[4] = {(u32)__builtin_amdgcn_readfirstlane((int)w.x), (u32)__builtin_amdgcn_readfirstlane((int)w.y),
                                            (u32)__builtin_amdgcn_readfirstlane((int)w.z), (u32)__builtin_amdgcn_readfirstlane((int)w.w)};
@@ -697,7 +809,16 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                         }
                     }
                     if ((int)blkmax > bestv) { bestv = (int)blkmax; bestblk = q; }
-                    lds_store(&lds.cons_blk[ls][ci], q);
+                    if constexpr (NC > 4) {
+                        // a slot shared by two consumers is published in block order: wait for the block before mine
+                        if (partner >= 0) {
+                            const int back = ((q - partner) % NC + NC) % NC;  // 1..NC-1: distance to the partner's latest block below q
+                            const int pred = (q - back >= 0) ? q - back : -1;
+                            while (lds_load(&lds.cons_blk[ls][slot]) != pred)
+                                if (spin.fail(p.abort_flag)) return;
+                        }
+                    }
+                    lds_store(&lds.cons_blk[ls][slot], q);
                 }
                 // arg-max: the lowest row of block `bestblk` holding bestv in my column (re-read what this wave stored)
                 if (cell_ok && !(p.debug_flags & 1) && bestv > 0) {
@@ -722,12 +843,15 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
             //         indexed by strip s0's local step: row t lives at entry (t + phi0 - 1) mod RH
             // export: lane-63 column of the group's last strip -> HBM granules for the next group
             const int slast = s0 + nact - 1;
+            __builtin_amdgcn_s_setprio(2);  // short, latency-critical loops: ahead of the consumers on their SIMD
             const bool do_export = (slast + 1 < p.nstrips);
             const int phi0 = phi_of(s0, phib), phil = phi_of(slast, phib);
             const u32 halo_row0 = (u32)((p.top ? p.top[(int64_t)s0 * SY_W] : 0) + ngap * s0 * SY_W);
             // import starts at row 0 (the diagonal neighbour of row 1); with the fast producers at the row of
             // strip s0's local step 1: the cells above the matrix hold the H == 0 floor there
             int imp = (phib >= 0) ? 1 - phi0 : 0, exp = 1;
+            bool imp_wide = true;
+            u64 pace_t0 = 0;
             Spin spin;
             auto edge_val = [&](int r, bool& ok) -> u32 {  // G of (row r, column 63*s0): the halo of strip s0
                 ok = true;
@@ -742,48 +866,62 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 bool progressed = false;
                 if (importer && imp <= rows) {
                     // halo[] holds RH steps and strip s0's producer has consumed every step <= its progress:
-                    // rows < lim may be written.  Up to 4 x 64 rows per round trip to HBM/L2.
-                    const int lim = min(rows + 1, lds_load(&lds.prod_u[0]) - phi0 + SY_RH - 2 * SY_U);
+                    // rows < lim may be written.  One 64-row window per round trip to HBM/L2 while the importer
+                    // rides the left neighbour's front (latency matters); four windows while it is catching up.
+                    int lim = min(rows + 1, lds_load(&lds.prod_u[0]) - phi0 + SY_RH - 2 * SY_U);
+                    if (s0 == 0 && p.pace_ps > 0) {
+                        // pacing: strip 0 runs a few percent below full speed, so every later strip has headroom to
+                        // win back what a late hand-off cost it (otherwise each hop keeps its worst delay for good)
+                        const u64 now = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+                        if (pace_t0 == 0) pace_t0 = now;
+                        lim = min(lim, 64 + (int)min((u64)0x7fffff00, (now - pace_t0) * 10000ull / (u64)p.pace_ps));
+                    }
                     int base = imp;
-                    u32 vals[4];
-                    bool oks[4];
-                    if (s0 > 0) {
-                        // branch-free: four granule loads in flight at once (clamped addresses), validity by selects
-                        u64 gr[4];
-                        const u64* eb = p.edge + (int64_t)(s0 - 1) * estride;
+                    auto import_windows = [&](auto NB) {
+                        constexpr int nbat = decltype(NB)::value;
+                        u32 vals[nbat];
+                        bool oks[nbat];
+                        if (s0 > 0) {
+                            // branch-free: all granule loads in flight at once (clamped addresses), validity by selects
+                            u64 gr[nbat];
+                            const u64* eb = p.edge + (int64_t)(s0 - 1) * estride;
 #pragma unroll
-                        for (int b4 = 0; b4 < 4; ++b4) {
+                            for (int b4 = 0; b4 < nbat; ++b4) {
+                                const int r = imp + b4 * 64 + lane;
+                                gr[b4] = __hip_atomic_load((gu64*)(eb + min(max(r, 1), rows)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#pragma unroll
+                            for (int b4 = 0; b4 < nbat; ++b4) {
+                                const int r = imp + b4 * 64 + lane;
+                                const bool tag_ok = (gr[b4] >> 32) == (tag_base | (u64)(u32)max(r, 1));
+                                const u32 above = (r == 0) ? halo_row0 : (u32)(ngap * (r + s0 * SY_W));   // rows <= 0: H == 0 floor / halo row
+                                vals[b4] = (r <= 0) ? above : (u32)gr[b4];
+                                oks[b4] = (r < lim) && (r <= 0 || tag_ok);
+                            }
+                        } else {
+#pragma unroll
+                            for (int b4 = 0; b4 < nbat; ++b4) {
+                                const int r = imp + b4 * 64 + lane;
+                                bool ok = false;
+                                vals[b4] = 0;
+                                if (r < lim) vals[b4] = edge_val(r, ok);
+                                oks[b4] = ok;
+                            }
+                        }
+#pragma unroll
+                        for (int b4 = 0; b4 < nbat; ++b4) {
                             const int r = imp + b4 * 64 + lane;
-                            gr[b4] = __hip_atomic_load((gu64*)(eb + min(max(r, 1), rows)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const u64 okm = __ballot(oks[b4]);
+                            const int npre = (okm == ~0ull) ? 64 : __builtin_ctzll(~okm);  // leading run of valid rows
+                            if (base == imp + b4 * 64 && npre > 0) {                       // contiguous with what is imported
+                                if (lane < npre) __hip_atomic_store(&lds.halo[(r + phi0 - 1) & (SY_RH - 1)], vals[b4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                base += npre;
+                            }
                         }
-#pragma unroll
-                        for (int b4 = 0; b4 < 4; ++b4) {
-                            const int r = imp + b4 * 64 + lane;
-                            const bool tag_ok = (gr[b4] >> 32) == (tag_base | (u64)(u32)max(r, 1));
-                            const u32 above = (r == 0) ? halo_row0 : (u32)(ngap * (r + s0 * SY_W));   // rows <= 0: H == 0 floor / halo row
-                            vals[b4] = (r <= 0) ? above : (u32)gr[b4];
-                            oks[b4] = (r < lim) && (r <= 0 || tag_ok);
-                        }
-                    } else {
-#pragma unroll
-                        for (int b4 = 0; b4 < 4; ++b4) {
-                            const int r = imp + b4 * 64 + lane;
-                            bool ok = false;
-                            vals[b4] = 0;
-                            if (r < lim) vals[b4] = edge_val(r, ok);
-                            oks[b4] = ok;
-                        }
-                    }
-#pragma unroll
-                    for (int b4 = 0; b4 < 4; ++b4) {
-                        const int r = imp + b4 * 64 + lane;
-                        const u64 okm = __ballot(oks[b4]);
-                        const int npre = (okm == ~0ull) ? 64 : __builtin_ctzll(~okm);  // leading run of valid rows
-                        if (base == imp + b4 * 64 && npre > 0) {                       // contiguous with what is imported
-                            if (lane < npre) __hip_atomic_store(&lds.halo[(r + phi0 - 1) & (SY_RH - 1)], vals[b4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            base += npre;
-                        }
-                    }
+                    };
+                    if (imp_wide) import_windows(std::integral_constant<int, 4>{});
+                    else import_windows(std::integral_constant<int, 1>{});
+                    imp_wide = (base - imp) >= 64;   // a full window came back: there may be more behind it
                     if (base > imp) {
                         asm volatile("" ::: "memory");  // LDS executes a wave's ops in order: data before counter
                         if (p.dbg && lane == 0 && imp <= rows / 2 && base > rows / 2) p.dbg[2 * p.nstrips + 8 + 2 * grp] = __builtin_amdgcn_s_memrealtime();
@@ -813,6 +951,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 }
                 if (!progressed && spin.fail(p.abort_flag)) return;
             }
+            __builtin_amdgcn_s_setprio(0);
             if (exporter && do_export) lds_store(&lds.exp_done, 0x7fffffff);
             if (importer) lds_store(&lds.halo_ready, 0x7fffffff);
         }
@@ -826,8 +965,13 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
 SW_INST(2, 2)
 SW_INST(2, 3)
 SW_INST(2, 4)
+SW_INST(2, 5)
 SW_INST(1, 2)
+SW_INST(1, 3)
 SW_INST(1, 4)
+SW_INST(1, 6)
+SW_INST(1, 8)
+SW_INST(2, 6)
 #undef SW_INST
 
 // bpad[front + i] = b[i] (bytes, zero padded) and bpad16[front + i] = b[i] (16-bit, padded with the
