@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--engine", type=int, default=0, help="0 systolic (default), 1 strip_scan")
     ap.add_argument("--ns", type=int, default=0, help="systolic: strips per workgroup")
     ap.add_argument("--nc", type=int, default=0, help="systolic: consumer waves per strip")
+    ap.add_argument("--store-policy", type=int, default=0, help="systolic H/P stores: 0 auto, 1 write-back, 2 streaming")
+    ap.add_argument("--xcd-order", type=int, default=0, help="systolic: neighbouring strip groups on one XCD")
     ap.add_argument("--pace", type=int, default=-1, help="systolic: strip-0 pacing in ps per row (0 = off, -1 = library default)")
     ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--wpb", type=int, default=0)
@@ -146,6 +148,10 @@ def main():
     eng.set_option("engine", args.engine)
     if args.pace >= 0:
         eng.set_option("pace_ps", args.pace)
+    if args.store_policy:
+        eng.set_option("store_policy", args.store_policy)
+    if args.xcd_order:
+        eng.set_option("xcd_order", args.xcd_order)
     if args.ns:
         eng.set_option("strips_per_group", args.ns)
     if args.nc:

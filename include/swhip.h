@@ -126,7 +126,15 @@ int sw_memcpy_h2d(sw_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int sw_memcpy_d2h(sw_ctx* ctx, void* dst, const void* d_src, size_t bytes);
 int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports kernel faults */
 
-/* ---- tuning knobs (0 = built-in default) -------------------------------------------------- */
+/* ---- tuning knobs (0 = built-in default) --------------------------------------------------
+ * None of them changes a result bit; they only move time.
+ *   "engine"            0 systolic (default), 1 strip_scan
+ *   "strips_per_group"  systolic: strips (producer waves) per workgroup, 1 or 2 (default 2)
+ *   "consumers"         systolic: consumer waves per strip: 2, 3, 4 (default 4); also 6, 8 with one strip per group
+ *   "store_policy"      systolic H/P stores: 0 by problem size, 1 write-back, 2 streaming (nt)
+ *   "xcd_order"         systolic: 1 = neighbouring strip groups run on the same XCD
+ *   "pace_ps"           systolic: strip 0 releases one row per this many picoseconds (0 = unpaced)
+ *   "waves_per_block", "max_blocks", "debug_flags", "debug_buf"   development aids */
 int sw_set_option(sw_ctx* ctx, const char* name, int64_t value);
 int64_t sw_get_option(sw_ctx* ctx, const char* name);
 

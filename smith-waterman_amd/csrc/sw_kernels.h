@@ -30,6 +30,8 @@ struct FillParams {
     int bfront;                // systolic: index of b[0] inside bpad / bpad16
     const unsigned short* bpad16;
     unsigned long long* dbg;   // optional: per strip {start, end} s_memrealtime stamps of its producer (experiments)
+    int store_nt;              // systolic: streaming (nt) H/P stores
+    int xcd_order;             // systolic: neighbouring strip groups on one XCD
     int pace_ps;               // systolic: strip 0 releases one row per pace_ps picoseconds (0 = unpaced)
     int debug_flags;           // bit0: drop the H/P stores (timing experiments only)
     int nstrips;               // strip_scan: ceil(cols/64); systolic: ceil(cols/63)

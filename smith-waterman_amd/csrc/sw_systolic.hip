@@ -449,25 +449,29 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
 // literal temporaries: v[100:115] H of the 16 rows, v[116:119] s', v[120:123] diagonal candidates,
 // v[124:127] P; s[60:75] compare masks, s[76:79] the row characters, s80 row byte offset
 // =================================================================================================
-#ifndef CB_POLICY
-#define CB_POLICY " nt"   /* streaming stores: H and P are written once and never re-read by the fill (measured -18% at 16384^2) */
-#endif
-#define CB_H(K, G)                                                                            \
+#define CB_H(POL, K, G)                                                                            \
     "v_add_u32 %[z], %[z], %[ngap]\n\t"                                                      \
     "v_sub_u32 v" #K ", %[" G "], %[z]\n\t"                                                   \
-    "buffer_store_dword v" #K ", %[voff], %[rH], s80 offen" CB_POLICY "\n\t"                              \
+    "buffer_store_dword v" #K ", %[voff], %[rH], s80 offen" POL "\n\t"                              \
     "s_add_u32 s80, s80, %[stride]\n\t"
+// int64 H: the score is never negative, so the high dword is a zero register paired with each H register
+#define CB_H64(POL, K, K1, G)                                                                 \
+    "v_add_u32 %[z], %[z], %[ngap]\n\t"                                                      \
+    "v_sub_u32 v" #K ", %[" G "], %[z]\n\t"                                                   \
+    "v_mov_b32 v" #K1 ", 0\n\t"                                                              \
+    "buffer_store_dwordx2 v[" #K ":" #K1 "], %[voffH], %[rH], s81 offen" POL "\n\t"           \
+    "s_add_u32 s81, s81, %[strideH]\n\t"
 #define CB_PRED(G, UP, DD, M1, M3)                                                            \
     "v_cmp_eq_u32_e64 " M1 ", %[" UP "], %[" G "]\n\t"                                       \
     "v_cmp_eq_u32_e64 " M3 ", " DD ", %[" G "]\n\t"
-#define CB_SEL(HK, PI, M1, M3)                                                                \
+#define CB_SEL(POL, HK, PI, M1, M3)                                                                \
     "v_cmp_eq_u32_e32 vcc, 0, " HK "\n\t"                                                    \
     "v_cndmask_b32_e64 " PI ", 2, 1, " M1 "\n\t"                                             \
     "v_cndmask_b32_e64 " PI ", " PI ", 3, " M3 "\n\t"                                        \
     "v_cndmask_b32_e64 " PI ", " PI ", 0, vcc\n\t"                                           \
-    "buffer_store_dword " PI ", %[voff], %[rP], s80 offen" CB_POLICY "\n\t"                               \
+    "buffer_store_dword " PI ", %[voff], %[rP], s80 offen" POL "\n\t"                               \
     "s_add_u32 s80, s80, %[stride]\n\t"
-#define CB_GROUP(CH, U, G0, G1, G2, G3, H0, H1, H2, H3)                                       \
+#define CB_GROUP(POL, CH, U, G0, G1, G2, G3, H0, H1, H2, H3)                                       \
     "v_cmp_eq_u32_sdwa s[60:61], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_0\n\t"            \
     "v_cmp_eq_u32_sdwa s[62:63], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_1\n\t"            \
     "v_cmp_eq_u32_sdwa s[64:65], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_2\n\t"            \
@@ -482,43 +486,86 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
     "v_add_u32_dpp v123, %[" G2 "], v119 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
     CB_PRED(G0, U, "v120", "s[60:61]", "s[62:63]")                                            \
     CB_PRED(G1, G0, "v121", "s[64:65]", "s[66:67]")                                           \
-    CB_SEL(H0, "v124", "s[60:61]", "s[62:63]")                                                \
+    CB_SEL(POL, H0, "v124", "s[60:61]", "s[62:63]")                                                \
     CB_PRED(G2, G1, "v122", "s[68:69]", "s[70:71]")                                           \
-    CB_SEL(H1, "v125", "s[64:65]", "s[66:67]")                                                \
+    CB_SEL(POL, H1, "v125", "s[64:65]", "s[66:67]")                                                \
     CB_PRED(G3, G2, "v123", "s[72:73]", "s[74:75]")                                           \
-    CB_SEL(H2, "v126", "s[68:69]", "s[70:71]")                                                \
-    CB_SEL(H3, "v127", "s[72:73]", "s[74:75]")
+    CB_SEL(POL, H2, "v126", "s[68:69]", "s[70:71]")                                                \
+    CB_SEL(POL, H3, "v127", "s[72:73]", "s[74:75]")
 typedef int sw_i32x4 __attribute__((ext_vector_type(4)));
+#define CB_ASM(POL) \
+    asm volatile( \
+        "s_load_dwordx4 s[76:79], %[cptr], 0x0\n\t" \
+        "s_mov_b32 s80, 0\n\t" \
+        CB_H(POL, 100, "g1") CB_H(POL, 101, "g2") CB_H(POL, 102, "g3") CB_H(POL, 103, "g4") CB_H(POL, 104, "g5") CB_H(POL, 105, "g6") CB_H(POL, 106, "g7") CB_H(POL, 107, "g8") \
+        CB_H(POL, 108, "g9") CB_H(POL, 109, "g10") CB_H(POL, 110, "g11") CB_H(POL, 111, "g12") CB_H(POL, 112, "g13") CB_H(POL, 113, "g14") CB_H(POL, 114, "g15") CB_H(POL, 115, "g16") \
+        "v_max3_i32 %[bm], %[bm], v100, v101\n\t" \
+        "v_max3_i32 v116, v102, v103, v104\n\t" \
+        "v_max3_i32 v117, v105, v106, v107\n\t" \
+        "v_max3_i32 v118, v108, v109, v110\n\t" \
+        "v_max3_i32 v119, v111, v112, v113\n\t" \
+        "v_max3_i32 %[bm], %[bm], v114, v115\n\t" \
+        "v_max3_i32 v116, v116, v117, v118\n\t" \
+        "v_max3_i32 %[bm], %[bm], v116, v119\n\t" \
+        "s_mov_b32 s80, 0\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        CB_GROUP(POL, "s76", "g0", "g1", "g2", "g3", "g4", "v100", "v101", "v102", "v103") \
+        CB_GROUP(POL, "s77", "g4", "g5", "g6", "g7", "g8", "v104", "v105", "v106", "v107") \
+        CB_GROUP(POL, "s78", "g8", "g9", "g10", "g11", "g12", "v108", "v109", "v110", "v111") \
+        CB_GROUP(POL, "s79", "g12", "g13", "g14", "g15", "g16", "v112", "v113", "v114", "v115") \
+        : [z] "+v"(z), [bm] "+v"(blkmax) \
+        : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]), [g7] "v"(g[7]), \
+          [g8] "v"(g[8]), [g9] "v"(g[9]), [g10] "v"(g[10]), [g11] "v"(g[11]), [g12] "v"(g[12]), [g13] "v"(g[13]), [g14] "v"(g[14]), \
+          [g15] "v"(g[15]), [g16] "v"(g[16]), [a] "v"(a_l), [mm] "v"(mm_v), [xm] "v"(xm_v), [ngap] "v"(ngap_v), [voff] "v"(voff), \
+          [rH] "s"(rH), [rP] "s"(rP), [stride] "s"(stride), [cptr] "s"(chars) \
+        : "vcc", "scc", "memory", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", \
+          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", \
+          "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", \
+          "v124", "v125", "v126", "v127")
+// NT: streaming (nt) stores -- H and P are written once and never re-read by the fill; which policy is faster
+// depends on the problem size (measured: nt wins at 16384^2, plain write-back at 32768^2)
+template <bool NT>
 __device__ __forceinline__ void consumer_block16(const u32 (&g)[SY_U + 1], u32& z, u32& blkmax, u32 a_l, u32 mm_v, u32 xm_v, u32 ngap_v,
                                                  u32 voff, sw_i32x4 rH, sw_i32x4 rP, u32 stride, const unsigned char* chars) {
-    asm volatile(
-        "s_load_dwordx4 s[76:79], %[cptr], 0x0\n\t"
-        "s_mov_b32 s80, 0\n\t"
-        CB_H(100, "g1") CB_H(101, "g2") CB_H(102, "g3") CB_H(103, "g4") CB_H(104, "g5") CB_H(105, "g6") CB_H(106, "g7") CB_H(107, "g8")
-        CB_H(108, "g9") CB_H(109, "g10") CB_H(110, "g11") CB_H(111, "g12") CB_H(112, "g13") CB_H(113, "g14") CB_H(114, "g15") CB_H(115, "g16")
-        "v_max3_i32 %[bm], %[bm], v100, v101\n\t"
-        "v_max3_i32 v116, v102, v103, v104\n\t"
-        "v_max3_i32 v117, v105, v106, v107\n\t"
-        "v_max3_i32 v118, v108, v109, v110\n\t"
-        "v_max3_i32 v119, v111, v112, v113\n\t"
-        "v_max3_i32 %[bm], %[bm], v114, v115\n\t"
-        "v_max3_i32 v116, v116, v117, v118\n\t"
-        "v_max3_i32 %[bm], %[bm], v116, v119\n\t"
-        "s_mov_b32 s80, 0\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        CB_GROUP("s76", "g0", "g1", "g2", "g3", "g4", "v100", "v101", "v102", "v103")
-        CB_GROUP("s77", "g4", "g5", "g6", "g7", "g8", "v104", "v105", "v106", "v107")
-        CB_GROUP("s78", "g8", "g9", "g10", "g11", "g12", "v108", "v109", "v110", "v111")
-        CB_GROUP("s79", "g12", "g13", "g14", "g15", "g16", "v112", "v113", "v114", "v115")
-        : [z] "+v"(z), [bm] "+v"(blkmax)
-        : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]), [g7] "v"(g[7]),
-          [g8] "v"(g[8]), [g9] "v"(g[9]), [g10] "v"(g[10]), [g11] "v"(g[11]), [g12] "v"(g[12]), [g13] "v"(g[13]), [g14] "v"(g[14]),
-          [g15] "v"(g[15]), [g16] "v"(g[16]), [a] "v"(a_l), [mm] "v"(mm_v), [xm] "v"(xm_v), [ngap] "v"(ngap_v), [voff] "v"(voff),
-          [rH] "s"(rH), [rP] "s"(rP), [stride] "s"(stride), [cptr] "s"(chars)
-        : "vcc", "scc", "memory", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73",
-          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",
-          "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
-          "v124", "v125", "v126", "v127");
+    if constexpr (NT) { CB_ASM(" nt"); } else { CB_ASM(""); }
+}
+
+#define CB_ASM64(POL) \
+    asm volatile( \
+        "s_load_dwordx4 s[76:79], %[cptr], 0x0\n\t" \
+        "s_mov_b32 s81, 0\n\t" \
+        CB_H64(POL, 64, 65, "g1") CB_H64(POL, 66, 67, "g2") CB_H64(POL, 68, 69, "g3") CB_H64(POL, 70, 71, "g4") \
+        CB_H64(POL, 72, 73, "g5") CB_H64(POL, 74, 75, "g6") CB_H64(POL, 76, 77, "g7") CB_H64(POL, 78, 79, "g8") \
+        CB_H64(POL, 80, 81, "g9") CB_H64(POL, 82, 83, "g10") CB_H64(POL, 84, 85, "g11") CB_H64(POL, 86, 87, "g12") \
+        CB_H64(POL, 88, 89, "g13") CB_H64(POL, 90, 91, "g14") CB_H64(POL, 92, 93, "g15") CB_H64(POL, 94, 95, "g16") \
+        "v_max3_i32 %[bm], %[bm], v64, v66\n\t" \
+        "v_max3_i32 v116, v68, v70, v72\n\t" \
+        "v_max3_i32 v117, v74, v76, v78\n\t" \
+        "v_max3_i32 v118, v80, v82, v84\n\t" \
+        "v_max3_i32 v119, v86, v88, v90\n\t" \
+        "v_max3_i32 %[bm], %[bm], v92, v94\n\t" \
+        "v_max3_i32 v116, v116, v117, v118\n\t" \
+        "v_max3_i32 %[bm], %[bm], v116, v119\n\t" \
+        "s_mov_b32 s80, 0\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        CB_GROUP(POL, "s76", "g0", "g1", "g2", "g3", "g4", "v64", "v66", "v68", "v70") \
+        CB_GROUP(POL, "s77", "g4", "g5", "g6", "g7", "g8", "v72", "v74", "v76", "v78") \
+        CB_GROUP(POL, "s78", "g8", "g9", "g10", "g11", "g12", "v80", "v82", "v84", "v86") \
+        CB_GROUP(POL, "s79", "g12", "g13", "g14", "g15", "g16", "v88", "v90", "v92", "v94") \
+        : [z] "+v"(z), [bm] "+v"(blkmax) \
+        : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]), [g7] "v"(g[7]), \
+          [g8] "v"(g[8]), [g9] "v"(g[9]), [g10] "v"(g[10]), [g11] "v"(g[11]), [g12] "v"(g[12]), [g13] "v"(g[13]), [g14] "v"(g[14]), \
+          [g15] "v"(g[15]), [g16] "v"(g[16]), [a] "v"(a_l), [mm] "v"(mm_v), [xm] "v"(xm_v), [ngap] "v"(ngap_v), [voff] "v"(voff), \
+          [voffH] "v"(voffH), [rH] "s"(rH), [rP] "s"(rP), [stride] "s"(stride), [strideH] "s"(strideH), [cptr] "s"(chars) \
+        : "vcc", "scc", "memory", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", \
+          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", \
+          "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", \
+          "v92", "v93", "v94", "v95", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
+template <bool NT>
+__device__ __forceinline__ void consumer_block16_h64(const u32 (&g)[SY_U + 1], u32& z, u32& blkmax, u32 a_l, u32 mm_v, u32 xm_v,
+                                                     u32 ngap_v, u32 voff, u32 voffH, sw_i32x4 rH, sw_i32x4 rP, u32 stride, u32 strideH,
+                                                     const unsigned char* chars) {
+    if constexpr (NT) { CB_ASM64(" nt"); } else { CB_ASM64(""); }
 }
 
 template <typename HT, int NS, int NC>
@@ -538,7 +585,21 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
 
     const unsigned char* const seq_a0 = seq_a; const unsigned char* const seq_b0 = seq_b; const unsigned char* const bpad0 = bpad;
     const FillParams p0 = p;
-    for (int64_t gidx = blockIdx.x; gidx < (int64_t)ngroups * p0.npairs; gidx += gridDim.x) {
+    const int64_t ntotal = (int64_t)ngroups * p0.npairs;
+    for (int64_t gbase = 0; gbase < ntotal; gbase += gridDim.x) {
+        // Optional XCD-aware order inside one pass of gridDim.x workgroups (option xcd_order): the hardware deals
+        // workgroups to the 8 XCDs round-robin (blockIdx % 8); give neighbouring strip groups to one XCD so that
+        // cache lines straddling two strips can be completed inside one L2.
+        const int n_pass = (int)min((int64_t)gridDim.x, ntotal - gbase);
+        if ((int)blockIdx.x >= n_pass) break;
+        int local = (int)blockIdx.x;
+        if (p0.xcd_order && n_pass >= 16) {
+            const int x = (int)blockIdx.x & 7;
+            int off = 0;
+            for (int y = 0; y < x; ++y) off += (n_pass - y + 7) >> 3;
+            local = off + ((int)blockIdx.x >> 3);
+        }
+        const int64_t gidx = gbase + local;
         const int grp = (int)(gidx % ngroups);
         const int64_t pair = gidx / ngroups;
         // per-problem views (batch of independent pairs: BASELINE config 5)
@@ -776,13 +837,17 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                         if (right_lane) p.right[r0 + k] = (int)h;   // the tile's right edge column, for the next tile of this band
                     };
                     u32 blkmax = 0;
-                    if (sizeof(HT) == 4 && nb == SY_U && !right_strip) {
+                    if (nb == SY_U && !right_strip) {
                         // the common case: whole block in one asm statement
                         u32 z = (u32)(cz + ngap * (r0 - 1));
-                        const uint64_t bH = (uint64_t)(uintptr_t)((int32_t*)H + (int64_t)r0 * M), bP = (uint64_t)(uintptr_t)(P + (int64_t)r0 * M);
+                        const uint64_t bH = (uint64_t)(uintptr_t)(H + (int64_t)r0 * M), bP = (uint64_t)(uintptr_t)(P + (int64_t)r0 * M);
                         const sw_i32x4 dH = {(int)(u32)bH, (int)(u32)(bH >> 32), 0x7FFFFF00, 0x00020000};
                         const sw_i32x4 dP = {(int)(u32)bP, (int)(u32)(bP >> 32), 0x7FFFFF00, 0x00020000};
-                        consumer_block16(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, dH, dP, rowP, seq_b + (r0 - 1));
+                        if constexpr (sizeof(HT) == 8) {
+                            if (p.store_nt) consumer_block16_h64<true>(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, voffH, dH, dP, rowP, rowH, seq_b + (r0 - 1));
+                            else consumer_block16_h64<false>(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, voffH, dH, dP, rowP, rowH, seq_b + (r0 - 1));
+                        } else if (p.store_nt) consumer_block16<true>(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, dH, dP, rowP, seq_b + (r0 - 1));
+                        else consumer_block16<false>(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, dH, dP, rowP, seq_b + (r0 - 1));
                     } else if (nb == SY_U) {
                         const uint4 w = *reinterpret_cast<const uint4*>(seq_b + (r0 - 1));  // this block's 16 row characters
                         const u32 bw[4] = {(u32)__builtin_amdgcn_readfirstlane((int)w.x), (u32)__builtin_amdgcn_readfirstlane((int)w.y),
@@ -809,6 +874,8 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                         }
                     }
                     if ((int)blkmax > bestv) { bestv = (int)blkmax; bestblk = q; }
+                    if (p.dbg && (p.debug_flags & 128) && lane == 0)   // per-block completion stamps (after the strip stamps and counters)
+                        p.dbg[6 * p.nstrips + 64 + (int64_t)s * nblk + q] = __builtin_amdgcn_s_memrealtime();
                     if constexpr (NC > 4) {
                         // a slot shared by two consumers is published in block order: wait for the block before mine
                         if (partner >= 0) {
@@ -965,13 +1032,11 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
 SW_INST(2, 2)
 SW_INST(2, 3)
 SW_INST(2, 4)
-SW_INST(2, 5)
 SW_INST(1, 2)
 SW_INST(1, 3)
 SW_INST(1, 4)
 SW_INST(1, 6)
 SW_INST(1, 8)
-SW_INST(2, 6)
 #undef SW_INST
 
 // bpad[front + i] = b[i] (bytes, zero padded) and bpad16[front + i] = b[i] (16-bit, padded with the

@@ -143,6 +143,32 @@ def test_launch_shapes(engine, oracle, wpb, maxb):
         engine.set_option("max_blocks", 0)
 
 
+TUNINGS = [
+    {"strips_per_group": 2, "consumers": 2}, {"strips_per_group": 2, "consumers": 3}, {"strips_per_group": 1, "consumers": 2},
+    {"strips_per_group": 1, "consumers": 3}, {"strips_per_group": 1, "consumers": 4}, {"strips_per_group": 1, "consumers": 6},
+    {"strips_per_group": 1, "consumers": 8}, {"store_policy": 1}, {"store_policy": 2}, {"xcd_order": 1},
+    {"xcd_order": 1, "max_blocks": 20}, {"pace_ps": 40000}, {"store_policy": 2, "xcd_order": 1, "strips_per_group": 1, "consumers": 8},
+]
+
+
+@pytest.mark.parametrize("opts", TUNINGS, ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+@pytest.mark.parametrize("h64", [False, True], ids=["h32", "h64"])
+def test_tuning_options_do_not_change_results(engine, oracle, engine_kind, opts, h64):
+    """Workgroup shape, store cache policy, XCD order and pacing only move time: H, P and the arg-max stay bit-exact."""
+    if engine_kind != 0:
+        pytest.skip("systolic-engine options")
+    import torch
+    a, b = oracle.generate(4200, 1300, 21)   # 67 strips: enough groups for the XCD-aware order and a second pass
+    defaults = {k: engine.get_option(k) for k in opts}
+    for k, v in opts.items():
+        engine.set_option(k, v)
+    try:
+        check_against_oracle(engine, oracle, a, b, h_dtype=torch.int64 if h64 else None)
+    finally:
+        for k, v in defaults.items():
+            engine.set_option(k, v)
+
+
 def test_full_size_16384_streaming_checksums(engine, oracle, swamd):
     """BASELINE config 2 (16384 x 16384 int32): per-row checksums + arg-max vs the streaming oracle."""
     a, b = swamd.generate(16384, 16384, 1)
