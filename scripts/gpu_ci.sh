@@ -20,7 +20,13 @@ step smoke 300 python __graft_entry__.py smoke
 step pytest_gpu 600 python -m pytest tests -m gpu -x -q
 step bench 400 python bench.py --steps 10 --warmup 2
 step bench_strip_scan 200 python bench.py --steps 5 --warmup 1 --no-cpu --engine 1
-step bench_h64_32k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 32768 --rows 32768 --h64
+step bench_h64_32k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 32768 --rows 32768 --h64 --placement-trials 2
+step bench_h64_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64 --placement-trials 1
+step bench_i32_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --placement-trials 1
+step bench_batch_1k 300 python bench.py --steps 3 --warmup 1 --mode batch --cols 1024 --rows 1024 --pairs 100000
+step bench_batch_1k_stored 300 python bench.py --steps 3 --warmup 1 --mode batch --cols 1024 --rows 1024 --pairs 512 --store
 export TMPDIR=/tmp
-step rocprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 5 --warmup 1 --no-cpu
+# same command under the profiler; one placement only, so that every sw_systolic launch in the trace is a launch of the
+# timed configuration (the stats average is then comparable with the JSON line this run prints)
+step rocprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 20 --warmup 3 --no-cpu --placement-trials 1
 find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -8 "$f"; done

@@ -222,18 +222,20 @@ __device__ __forceinline__ int phi_of(int s, int phi_base) { return phi_base >= 
     "ds_write_b128 v126, v[100:103] offset:" O0 "\n\t"                                       \
     "s_waitcnt lgkmcnt(1)\n\t"                                                               \
     "ds_read_b128 v[108:111], v127 offset:" R2 "\n\t"                                        \
-    "ds_read_b32 v120, v56\n\t"                                                              \
     SF_ODD(C2, C3, "v116", "v117", "v118", "v119")                                           \
     "ds_write_b128 v126, v[104:107] offset:" O1 "\n\t"                                       \
-    "s_waitcnt lgkmcnt(2)\n\t"                                                               \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                               \
     "ds_read_b128 v[116:119], v127 offset:" R3 "\n\t"                                        \
-    "ds_read_b128 v[122:125], " RAN "\n\t"                                                   \
     SF_EVEN(C4, C5, "v108", "v109", "v110", "v111")                                          \
     "ds_write_b128 v126, v[100:103] offset:" O2 "\n\t"                                       \
-    "s_waitcnt lgkmcnt(2)\n\t"                                                               \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                               \
+    /* as late as the LDS latency allows: the left neighbour's progress, THEN (in order behind it) the next     \
+       block's first four halo values -- every step this look-ahead is shorter is a step less lag per strip */  \
+    "ds_read_b32 v120, v56\n\t"                                                              \
+    "ds_read_b128 v[122:125], " RAN "\n\t"                                                   \
     SF_ODD(C6, C7, "v116", "v117", "v118", "v119")                                           \
     "ds_write_b128 v126, v[104:107] offset:" O3 "\n\t"                                       \
-    "s_waitcnt lgkmcnt(2)\n\t"                                                               \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                               \
     "v_readfirstlane_b32 s85, v120\n\t"                                                      \
     "s_add_i32 s86, s88, %[k1]\n\t"                                                          \
     "s_min_i32 s86, s86, %[k2]\n\t"                                                          \
