@@ -186,6 +186,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # what a plain contiguous fill of H sustains on this box (reported beside the 8 TB/s spec peak)
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out.H.fill_(0); torch.cuda.synchronize()
+    f0.record()
+    for _ in range(5):
+        out.H.fill_(0)
+    f1.record(); torch.cuda.synchronize()
+    fill_gbs = 5 * out.H.numel() * out.H.element_size() / (f0.elapsed_time(f1) * 1e-3) / 1e9
+
     for _ in range(args.warmup):
         eng.fill_into(out, d_a, d_b)
     barrier()
@@ -229,7 +238,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "sw_systolic" if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
-                         "algorithmic_bytes_per_cell": bytes_per_cell},
+                         "algorithmic_bytes_per_cell": bytes_per_cell, "measured_contiguous_fill_GBs": fill_gbs},
         }
         if not args.no_cpu and world == 1:
             cb = cpu_baseline(cols, rows)
