@@ -451,10 +451,21 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
 // literal temporaries: v[100:115] H of the 16 rows, v[116:119] s', v[120:123] diagonal candidates,
 // v[124:127] P; s[60:75] compare masks, s[76:79] the row characters, s80 row byte offset
 // =================================================================================================
+// A/B hooks: -DCB_FORCE_H='" nt"' / -DCB_FORCE_P='""' pin the cache policy of the H or P stores
+#ifdef CB_FORCE_H
+#define CB_POLH(POL) CB_FORCE_H
+#else
+#define CB_POLH(POL) POL
+#endif
+#ifdef CB_FORCE_P
+#define CB_POLP(POL) CB_FORCE_P
+#else
+#define CB_POLP(POL) POL
+#endif
 #define CB_H(POL, K, G)                                                                            \
     "v_add_u32 %[z], %[z], %[ngap]\n\t"                                                      \
     "v_sub_u32 v" #K ", %[" G "], %[z]\n\t"                                                   \
-    "buffer_store_dword v" #K ", %[voff], %[rH], s80 offen" POL "\n\t"                              \
+    "buffer_store_dword v" #K ", %[voff], %[rH], s80 offen" CB_POLH(POL) "\n\t"                              \
     "s_add_u32 s80, s80, %[stride]\n\t"
 // int64 H: the score is never negative, so the high dword is a zero register paired with each H register
 #define CB_H64(POL, K, K1, G)                                                                 \
@@ -471,7 +482,7 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
     "v_cndmask_b32_e64 " PI ", 2, 1, " M1 "\n\t"                                             \
     "v_cndmask_b32_e64 " PI ", " PI ", 3, " M3 "\n\t"                                        \
     "v_cndmask_b32_e64 " PI ", " PI ", 0, vcc\n\t"                                           \
-    "buffer_store_dword " PI ", %[voff], %[rP], s80 offen" POL "\n\t"                               \
+    "buffer_store_dword " PI ", %[voff], %[rP], s80 offen" CB_POLP(POL) "\n\t"                               \
     "s_add_u32 s80, s80, %[stride]\n\t"
 #define CB_GROUP(POL, CH, U, G0, G1, G2, G3, H0, H1, H2, H3)                                       \
     "v_cmp_eq_u32_sdwa s[60:61], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_0\n\t"            \
