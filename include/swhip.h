@@ -56,6 +56,12 @@ const char* sw_version(void);
  * seed 1 == serial_smithW.c (which never calls srand).  a holds cols+1 bytes, b rows+1. */
 int sw_generate(int64_t cols, int64_t rows, uint32_t seed, char* a, char* b);
 
+/* FASTA input, the step before the path for real sequences (the reference only has
+ * generate()).  Reads record `record` (0-based) of the file: '>' starts a record, ';' lines are comments,
+ * white space is dropped, letters are upper-cased; a file without '>' is one record.  *len receives the
+ * sequence length; seq (may be NULL to query the length) receives at most cap bytes, no terminator. */
+int sw_read_fasta(const char* path, int64_t record, char* seq, int64_t cap, int64_t* len);
+
 /* ---- wavefront indexing: nElement / calcFirstDiagElement, omp_smithW.c:260-275, 282-291.
  * m, n are the padded sizes (cols+1, rows+1); i in [1, m+n-3]. */
 int64_t sw_nelement(int64_t i, int64_t m, int64_t n);

@@ -46,6 +46,7 @@ ABI = {
     "sw_last_error": (ctypes.c_char_p, []),
     "sw_version": (ctypes.c_char_p, []),
     "sw_generate": (_i32, [_i64, _i64, _u32, _vp, _vp]),
+    "sw_read_fasta": (_i32, [ctypes.c_char_p, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
     "sw_nelement": (_i64, [_i64, _i64, _i64]),
     "sw_first_diag_element": (None, [_i64, _i64, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "sw_create": (_i32, [_i32, ctypes.POINTER(_vp)]),
@@ -100,6 +101,15 @@ def generate(cols: int, rows: int, seed: int = 1):
     b = np.zeros(rows + 1, np.uint8)
     _check(lib().sw_generate(cols, rows, seed, a.ctypes.data, b.ctypes.data))
     return a[:cols].copy(), b[:rows].copy()
+
+
+def read_fasta(path: str, record: int = 0):
+    """One record of a FASTA file as a uint8 array (upper-cased, white space dropped); see sw_read_fasta."""
+    n = _i64()
+    _check(lib().sw_read_fasta(os.fsencode(path), record, None, 0, ctypes.byref(n)))
+    seq = np.zeros(max(1, n.value), np.uint8)
+    _check(lib().sw_read_fasta(os.fsencode(path), record, seq.ctypes.data, n.value, ctypes.byref(n)))
+    return seq[:n.value].copy()
 
 
 def n_element(i: int, m: int, n: int) -> int:

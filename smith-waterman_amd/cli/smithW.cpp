@@ -1,7 +1,8 @@
 // smithW -- host driver with the reference's command line (serial_smithW.c:71-180, omp_smithW.c:87-253):
 //   smithW                  built-in 8x9 example (serial_smithW.c:105-125) + its known-answer checks
 //   smithW <cols> <rows>    random DNA pair from the reference generator (seed 1 == serial_smithW.c)
-// Extra flags (after the positional ones): --seed N  --dump  --h64  --no-backtrack  --scores M X G
+//   smithW --fasta A.fa B.fa   real sequences: a = first record of A.fa (columns), b = first record of B.fa (rows)
+// Extra flags (after the positional ones): --seed N  --dump  --h64  --no-backtrack  --scores M X G  --record-a I  --record-b J
 // The DP fill runs on the GPU through the C-ABI (include/swhip.h); stdout keeps the two
 // "Elapsed time ..." lines the reference's run scripts grep for (readme.liao:12).
 #include <chrono>
@@ -49,6 +50,8 @@ int main(int argc, char** argv) {
     long long cols = 8, rows = 9;
     bool builtin = true, dump = false, h64 = false, backtrack = true;
     unsigned seed = 1;
+    const char *fasta_a = nullptr, *fasta_b = nullptr;
+    long long rec_a = 0, rec_b = 0;
     sw_scores sc = {3, -3, -2};
     int ai = 1;
     if (argc >= 3 && argv[1][0] != '-' && argv[2][0] != '-') {
@@ -62,13 +65,26 @@ int main(int argc, char** argv) {
         if (f == "--dump") dump = true;
         else if (f == "--h64") h64 = true;
         else if (f == "--no-backtrack") backtrack = false;
+        else if (f == "--fasta" && ai + 2 < argc) { fasta_a = argv[++ai]; fasta_b = argv[++ai]; builtin = false; }
+        else if (f == "--record-a" && ai + 1 < argc) rec_a = strtoll(argv[++ai], nullptr, 10);
+        else if (f == "--record-b" && ai + 1 < argc) rec_b = strtoll(argv[++ai], nullptr, 10);
         else if (f == "--seed" && ai + 1 < argc) seed = (unsigned)strtoul(argv[++ai], nullptr, 10);
         else if (f == "--scores" && ai + 3 < argc) { sc.match = atoi(argv[++ai]); sc.mismatch = atoi(argv[++ai]); sc.gap = atoi(argv[++ai]); }
-        else { fprintf(stderr, "usage: smithW [<cols> <rows>] [--seed N] [--dump] [--h64] [--no-backtrack] [--scores M X G]\n"); return 2; }
+        else { fprintf(stderr, "usage: smithW [<cols> <rows> | --fasta A.fa B.fa [--record-a I] [--record-b J]] [--seed N] [--dump] [--h64] [--no-backtrack] [--scores M X G]\n"); return 2; }
+    }
+    if (fasta_a) {
+        int64_t la = 0, lb = 0;
+        CHECK(sw_read_fasta(fasta_a, rec_a, nullptr, 0, &la));
+        CHECK(sw_read_fasta(fasta_b, rec_b, nullptr, 0, &lb));
+        cols = la; rows = lb;
     }
     const long long m = cols + 1, n = rows + 1;
     std::vector<char> a(m + 1), b(n + 1);
-    if (builtin) { memcpy(b.data(), "GGTTGACTA", 9); memcpy(a.data(), "TGTTACGG", 8); }
+    if (fasta_a) {
+        int64_t la = 0, lb = 0;
+        CHECK(sw_read_fasta(fasta_a, rec_a, a.data(), cols, &la));
+        CHECK(sw_read_fasta(fasta_b, rec_b, b.data(), rows, &lb));
+    } else if (builtin) { memcpy(b.data(), "GGTTGACTA", 9); memcpy(a.data(), "TGTTACGG", 8); }
     else CHECK(sw_generate(cols, rows, seed, a.data(), b.data()));
     if (dump) { if (builtin) printf("\n Using built-in data for testing .."); printf("\nMatrix[%lld][%lld]\n", rows, cols); }
 

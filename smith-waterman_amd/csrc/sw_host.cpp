@@ -96,4 +96,37 @@ int sw_traceback_host(int32_t* P, int64_t cols, int64_t rows, int64_t max_pos, i
     return SW_OK;
 }
 
+// FASTA reader: the step before the path when the input is a real sequence instead of generate()
+// (SURVEY.md 8f-1).  '>' starts a record, ';' lines are comments, white space is dropped, letters are
+// upper-cased; a file without any '>' line is one record.
+int sw_read_fasta(const char* path, int64_t record, char* seq, int64_t cap, int64_t* len) {
+    if (!path || record < 0 || !len || (seq && cap < 0)) { swh::set_err("sw_read_fasta: bad argument"); return SW_EINVAL; }
+    FILE* f = fopen(path, "rb");
+    if (!f) { swh::set_err("sw_read_fasta: cannot open %s", path); return SW_EINVAL; }
+    int64_t cur = -1, n = 0;       // cur: index of the record being read (-1: before the first header)
+    bool at_line_start = true, skip_line = false, found = false;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) {
+        for (size_t i = 0; i < got; ++i) {
+            const unsigned char ch = (unsigned char)buf[i];
+            if (ch == '\n' || ch == '\r') { at_line_start = true; skip_line = false; continue; }
+            if (at_line_start) {
+                at_line_start = false;
+                if (ch == '>') { ++cur; skip_line = true; if (cur == record) found = true; continue; }
+                if (ch == ';') { skip_line = true; continue; }
+                if (cur < 0) { cur = 0; if (record == 0) found = true; }   // headerless file: a single record
+            }
+            if (skip_line || cur != record || ch == ' ' || ch == '\t') continue;
+            if (seq && n < cap) seq[n] = (char)((ch >= 'a' && ch <= 'z') ? ch - 32 : ch);
+            ++n;
+        }
+        if (cur > record) break;
+    }
+    fclose(f);
+    if (!found) { swh::set_err("sw_read_fasta: %s has no record %lld", path, (long long)record); return SW_EINVAL; }
+    *len = n;
+    return SW_OK;
+}
+
 }  // extern "C"

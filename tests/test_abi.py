@@ -62,6 +62,29 @@ def test_traceback_host_matches_reference(swamd, name):
     assert np.array_equal(P, g["P1"]) and np.array_equal(path, g["path"])
 
 
+def test_read_fasta(swamd, tmp_path):
+    """sw_read_fasta: records, comments, wrapped lines, lower case, CRLF, headerless files, missing records."""
+    f = tmp_path / "x.fa"
+    f.write_bytes(b";comment\n>seq1 first\nACGT\nacgt \r\nNN\n>seq2\n\nTT\tGG\n>empty\n>last\nA")
+    assert bytes(swamd.read_fasta(str(f))) == b"ACGTACGTNN"
+    assert bytes(swamd.read_fasta(str(f), 1)) == b"TTGG"
+    assert bytes(swamd.read_fasta(str(f), 2)) == b""
+    assert bytes(swamd.read_fasta(str(f), 3)) == b"A"
+    with pytest.raises(swamd.SwError):
+        swamd.read_fasta(str(f), 4)
+    with pytest.raises(swamd.SwError):
+        swamd.read_fasta(str(tmp_path / "missing.fa"))
+    g = tmp_path / "plain.txt"
+    g.write_bytes(b"GATTACA\nGATT\n")
+    assert bytes(swamd.read_fasta(str(g))) == b"GATTACAGATT"
+    with pytest.raises(swamd.SwError):
+        swamd.read_fasta(str(g), 1)
+    n = ctypes.c_int64()
+    buf = ctypes.create_string_buffer(4)
+    assert swamd.lib().sw_read_fasta(str(f).encode(), 0, buf, 4, ctypes.byref(n)) == 0   # truncated copy, full length reported
+    assert n.value == 10 and buf.raw == b"ACGT"
+
+
 def test_argument_errors(swamd):
     L = swamd.lib()
     assert L.sw_generate(-1, 4, 1, None, None) == -22 and b"sw_generate" in L.sw_last_error()

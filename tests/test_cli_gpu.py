@@ -60,3 +60,20 @@ def test_bad_usage_and_scores():
     assert run("--bogus").returncode == 2
     r = run("7", "5", "--scores", "5", "-3", "-4", "--dump")
     assert r.returncode == 0 and "Similarity Matrix" in r.stdout
+
+
+def test_fasta_input_matches_oracle(oracle, tmp_path):
+    """Real sequences instead of generate(): --fasta A B, then the same dump / known-answer path."""
+    rng = np.random.default_rng(5)
+    a = rng.choice(list(b"ACGT"), 300).astype(np.uint8)
+    b = np.concatenate([a[40:220], rng.choice(list(b"ACGT"), 60).astype(np.uint8)])
+    fa, fb = tmp_path / "a.fa", tmp_path / "b.fa"
+    fa.write_bytes(b">a\n" + b"\n".join(bytes(a[i:i + 70]) for i in range(0, len(a), 70)) + b"\n")
+    fb.write_bytes(b">skip\nAAAA\n>b\n" + bytes(b).lower() + b"\n")
+    r = run("--fasta", str(fa), str(fb), "--record-b", "1", "--dump")
+    assert r.returncode == 0, r.stderr
+    H, P = matrices(r.stdout)
+    oH, oP, mp = oracle.fill(a, b)
+    assert H.shape == (len(b) + 1, len(a) + 1) and np.array_equal(H, oH)
+    assert f"maxPos = {mp}, H[maxPos] = {int(oH.flat[mp])}" in r.stdout or str(mp) in r.stdout
+    assert run("--fasta", str(fa), str(tmp_path / "nope.fa")).returncode != 0
