@@ -1,9 +1,13 @@
-for i in 1 2 3; do python bench.py --no-cpu --steps 20 --warmup 3 2>&1 | python3 -c "
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 || exit 1
+for i in 1 2 3; do
+for v in base prev; do
+  if [ $v = base ]; then unset SWHIP_LIBRARY; else export SWHIP_LIBRARY=$PWD/build/libswhip_$v.so; fi
+  echo -n "$v: "; python bench.py --no-cpu --steps 20 --warmup 3 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); t=d['config']['placement_trials_ms']; print('%.1f GCUPS  [%s]'%(d['value'],' '.join('%.2f'%x for x in t)))
-"; done
-python bench.py --no-cpu --steps 20 --warmup 3 --placement-trials 1 2>&1 | grep -o '"value": [0-9.]*'
-python bench.py --no-cpu --steps 10 --warmup 2 --cols 8192 --rows 8192 2>&1 | grep -o '"value": [0-9.]*\|"placement_trials_ms": [^]]*]' | tr '\n' ' '; echo
-python bench.py --no-cpu --steps 5 --warmup 2 --cols 32768 --rows 32768 --placement-trials 3 2>&1 | grep -o '"value": [0-9.]*\|"placement_trials_ms": [^]]*]' | tr '\n' ' '; echo
+        d=json.loads(l); t=d['config']['placement_trials_ms']; print('%.1f GCUPS  [%s]'%(d['value'],' '.join('%.3f'%x for x in t)))
+"
+done; done
+unset SWHIP_LIBRARY
+python scripts/strip_times.py 16384 16384 0 2 4 2>&1 | grep -E "^   0:|hops|last end|strips mean"

@@ -210,7 +210,7 @@ __device__ __forceinline__ int phi_of(int s, int phi_base) { return phi_base >= 
 // one 16-step block.  KB: first step's index in the chunk; C0..C7: this block's character dwords;
 // NB: the buffer (tuples) that receives the characters of the block three ahead; PF: their byte offset;
 // RAN: where the next block's first four halo values are read from
-#define SF_BLOCK(KB, O0, O1, O2, O3, R1, R2, R3, C0, C1, C2, C3, C4, C5, C6, C7, NBA, NBB, PF0, PF1, RAN) \
+#define SF_BLOCK(KB, O0, O1, O2, O3, R1, R2, R3, C0, C1, C2, C3, C4, C5, C6, C7, NBA, NBB, PF0, PF1, RAN, BPF) \
     "s_cmp_eq_u32 s84, 0\n\t"                                                                \
     "s_cbranch_scc1 Lslow" #KB "_%=\n"                                                       \
     "Lgo" #KB "_%=:\n\t"                                                                     \
@@ -233,6 +233,7 @@ __device__ __forceinline__ int phi_of(int s, int phi_base) { return phi_base >= 
        block's first four halo values -- every step this look-ahead is shorter is a step less lag per strip */  \
     "ds_read_b32 v120, v56\n\t"                                                              \
     "ds_read_b128 v[122:125], " RAN "\n\t"                                                   \
+    BPF                                                                                      \
     SF_ODD(C6, C7, "v116", "v117", "v118", "v119")                                           \
     "ds_write_b128 v126, v[104:107] offset:" O3 "\n\t"                                       \
     "s_waitcnt lgkmcnt(1)\n\t"                                                               \
@@ -247,6 +248,41 @@ __device__ __forceinline__ int phi_of(int s, int phi_base) { return phi_base >= 
     "s_add_i32 s88, s88, 16\n\t"                                                             \
     "s_cmp_gt_i32 s88, %[ut]\n\t"                                                            \
     "s_cbranch_scc1 Lexit_%=\n\t"
+// Ring back-pressure, every 32 steps: my consumers (four counters) and my right-hand reader (the next producer or
+// the exporter) must be done with the slots of the coming 32 steps.  The counters were fetched from LDS during the
+// block before (SF_BPFETCH: no LDS round trip on the fast path); only a failed check re-reads them and polls.
+#define SF_BPFETCH "ds_read_b128 v[60:63], v57\n\tds_read_b32 v97, v58\n\t"
+#define SF_BPCHECK(T)                                                                         \
+    "v_min_i32 v116, v60, v61\n\t"                                                           \
+    "v_min3_i32 v116, v116, v62, v63\n\t"                                                    \
+    "s_mov_b32 s89, 0\n\t"                                                                   \
+    "v_readfirstlane_b32 s86, v97\n\t"                                                       \
+    "v_readfirstlane_b32 s85, v116\n"                                                        \
+    "Lbpe" T "_%=:\n\t"                                                                      \
+    "s_lshl_b32 s85, s85, 4\n\t"                                                             \
+    "s_add_i32 s85, s85, 16\n\t"                                                             \
+    "s_add_i32 s87, s88, %[kc]\n\t"                                                          \
+    "s_cmp_ge_i32 s85, s87\n\t"                                                              \
+    "s_cbranch_scc0 Lbpw" T "_%=\n\t"                                                        \
+    "s_add_i32 s87, s88, %[kr]\n\t"                                                          \
+    "s_cmp_ge_i32 s86, s87\n\t"                                                              \
+    "s_cbranch_scc1 Lbpok" T "_%=\n"                                                         \
+    "Lbpw" T "_%=:\n\t"                                                                      \
+    "s_sleep 1\n\t"                                                                          \
+    "s_add_i32 s89, s89, 1\n\t"                                                              \
+    "s_add_i32 s94, s94, 1\n\t"                                                              \
+    "s_cmp_lt_u32 s89, 0x1000000\n\t"                                                        \
+    "s_cbranch_scc0 Lbpfail_%=\n\t"                                                          \
+    "ds_read_b128 v[116:119], v57\n\t"                                                       \
+    "ds_read_b32 v120, v58\n\t"                                                              \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+    "v_min_i32 v116, v116, v117\n\t"                                                         \
+    "v_min3_i32 v116, v116, v118, v119\n\t"                                                  \
+    "s_nop 0\n\t"                                                                            \
+    "v_readfirstlane_b32 s85, v116\n\t"                                                      \
+    "v_readfirstlane_b32 s86, v120\n\t"                                                      \
+    "s_branch Lbpe" T "_%=\n"                                                                \
+    "Lbpok" T "_%=:\n\t"
 // out-of-line: wait until the left neighbour has produced this block's halo, then fetch its first group
 #define SF_SLOW(KB, R0)                                                                       \
     "Lslow" #KB "_%=:\n\t"                                                                   \
@@ -296,6 +332,11 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
         "v_sub_u32 v106, %[z0], %[ngap]\n\t"      /* step -1 */
         "v_mov_b32 v112, 0xe0000000\n\t"
         "v_mov_b32 v114, %[z0]\n\t"
+        "v_mov_b32 v60, 0\n\t"                   /* back-pressure counters as seen "before the start": nothing to wait for */
+        "v_mov_b32 v61, 0\n\t"
+        "v_mov_b32 v62, 0\n\t"
+        "v_mov_b32 v63, 0\n\t"
+        "v_mov_b32 v97, 0\n\t"
         "s_nop 4\n\t"
         "global_load_dwordx4 v[64:67], v96, s[92:93] offset:0\n\t"
         "global_load_dwordx4 v[68:71], v96, s[92:93] offset:16\n\t"
@@ -304,34 +345,7 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
         "global_load_dwordx4 v[80:83], v96, s[92:93] offset:64\n\t"
         "global_load_dwordx4 v[84:87], v96, s[92:93] offset:80\n"
         "Lchunk_%=:\n\t"
-        // ---- ring back-pressure, once per 64 steps: my consumers and my right-hand reader
-        "s_mov_b32 s89, 0\n"
-        "Lbp_%=:\n\t"
-        "ds_read_b128 v[116:119], v57\n\t"
-        "ds_read_b32 v120, v58\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_min_i32 v116, v116, v117\n\t"
-        "v_min3_i32 v116, v116, v118, v119\n\t"
-        "s_nop 0\n\t"
-        "v_readfirstlane_b32 s85, v116\n\t"
-        "v_readfirstlane_b32 s86, v120\n\t"
-        "s_lshl_b32 s85, s85, 4\n\t"
-        "s_add_i32 s85, s85, 16\n\t"
-        "s_add_i32 s87, s88, %[kc]\n\t"
-        "s_cmp_ge_i32 s85, s87\n\t"
-        "s_cbranch_scc0 Lbpw_%=\n\t"
-        "s_add_i32 s87, s88, %[kr]\n\t"
-        "s_cmp_ge_i32 s86, s87\n\t"
-        "s_cbranch_scc1 Lbpok_%=\n"
-        "Lbpw_%=:\n\t"
-        "s_sleep 1\n\t"
-        "s_add_i32 s89, s89, 1\n\t"
-        "s_add_i32 s94, s94, 1\n\t"
-        "s_cmp_lt_u32 s89, 0x1000000\n\t"
-        "s_cbranch_scc1 Lbp_%=\n\t"
-        "s_mov_b32 %[status], 2\n\t"
-        "s_branch Lexit_%=\n"
-        "Lbpok_%=:\n\t"
+        SF_BPCHECK("A")
         // ---- this chunk's LDS addresses: ring write base, halo read base, next chunk's halo read base
         "v_add_u32 v126, s90, %[wbase]\n\t"
         "v_mov_b32 v127, %[hbase]\n\t"
@@ -341,19 +355,22 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
         "v_mov_b32 v115, %[hbase]\n\t"
         "v_add_u32 v115, s91, v115\n\t"
         SF_BLOCK(0, "0", "16", "32", "48", "16", "32", "48", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71",
-                 "v[88:91]", "v[92:95]", "96", "112", "v127 offset:64")
+                 "v[88:91]", "v[92:95]", "96", "112", "v127 offset:64", "")
         SF_BLOCK(16, "64", "80", "96", "112", "80", "96", "112", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79",
-                 "v[64:67]", "v[68:71]", "128", "144", "v127 offset:128")
+                 "v[64:67]", "v[68:71]", "128", "144", "v127 offset:128", SF_BPFETCH)
+        SF_BPCHECK("B")
         SF_BLOCK(32, "128", "144", "160", "176", "144", "160", "176", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87",
-                 "v[72:75]", "v[76:79]", "160", "176", "v127 offset:192")
+                 "v[72:75]", "v[76:79]", "160", "176", "v127 offset:192", "")
         SF_BLOCK(48, "192", "208", "224", "240", "208", "224", "240", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
-                 "v[80:83]", "v[84:87]", "192", "208", "v115")
+                 "v[80:83]", "v[84:87]", "192", "208", "v115", SF_BPFETCH)
         "s_add_i32 s90, s90, 256\n\t"
         "s_and_b32 s90, s90, 1023\n\t"
         "s_add_u32 s92, s92, 128\n\t"
         "s_addc_u32 s93, s93, 0\n\t"
         "s_branch Lchunk_%=\n"
         SF_SLOW(0, "0") SF_SLOW(16, "64") SF_SLOW(32, "128") SF_SLOW(48, "192")
+        "Lbpfail_%=:\n\t"
+        "s_mov_b32 %[status], 2\n"
         "Lexit_%=:\n\t"
         "s_setprio 0\n\t"
         "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
@@ -364,7 +381,7 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
           [cbase] "s"(cbase), [hbase] "s"(hbase), [hoff4] "s"(hoff4), [cntaddr] "s"(cnt_addr), [consaddr] "s"(cons_addr),
           [rightaddr] "s"(right_addr), [progaddr] "s"(prog_addr), [ut] "s"(UT), [k1] "s"(k1), [k2] "s"(k2), [kc] "s"(kc), [kr] "s"(kr), [hmask] "s"(hmask)
         : "vcc", "scc", "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
-          "v56", "v57", "v58", "v59", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+          "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v97", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
           "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91",
           "v92", "v93", "v94", "v95", "v96", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
           "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
@@ -686,10 +703,10 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                     const u32 z0 = (u32)(ngap * (0 - phi + s * SY_W));            // floor of local step 0
                     const int k1 = lefthalo ? 2 * SY_U : 2 * SY_U - 1 + hoff;     // next block readable when left >= min(u0+k1, k2)
                     const int k2 = lefthalo ? rows + phi + 1 : left_total;
-                    const int kc = 62 - SY_R - phi;
+                    const int kc = 30 - SY_R - phi;           // back-pressure is checked every 32 steps
                     // my lane-63 entries of steps <= uc-193 get overwritten: the right-hand producer read them at its
                     // local step (mine - 64); the exporter counts ROWS (= my step - 63 - phi)
-                    const int kr = has_right ? -(SY_R + 1) + 16 : -SY_R - phi;
+                    const int kr = (has_right ? -(SY_R + 1) + 16 : -SY_R - phi) - 32;
                     int polls[2];
                     const int st = producer_fast(a_l, xm_v, mm_v, ngap_v, wbase, voff, z0, p.bpad16, hbase, hoff * 4, cnt_addr,
                                                  (u32)(size_t)&lds.cons_blk[ls][0], (u32)(size_t)right_cnt, (u32)(size_t)&lds.prod_u[ls],
