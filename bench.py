@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--engine", type=int, default=0, help="0 systolic (default), 1 strip_scan")
     ap.add_argument("--ns", type=int, default=0, help="systolic: strips per workgroup")
     ap.add_argument("--nc", type=int, default=0, help="systolic: consumer waves per strip")
-    ap.add_argument("--placement-trials", type=int, default=8,
+    ap.add_argument("--placement-trials", type=int, default=12,
                     help="pair mode: candidate H/P allocations tried before the timed region (1 = take the first)")
     ap.add_argument("--store-policy", type=int, default=0, help="systolic H/P stores: 0 auto, 1 write-back, 2 streaming")
     ap.add_argument("--xcd-order", type=int, default=0, help="systolic: neighbouring strip groups on one XCD")

@@ -244,6 +244,8 @@ class Engine:
             held.append(cand)       # keep every candidate alive so the next one lands somewhere else
             if ms < best_ms:
                 best, best_ms = cand, ms
+            if len(seen) >= 3 and best_ms < 0.92 * sorted(seen)[len(seen) // 2]:
+                break               # clearly in the fast mode: stop looking
         held.clear()
         t.cuda.empty_cache()
         return best, seen
