@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--engine", type=int, default=0, help="0 systolic (default), 1 strip_scan")
     ap.add_argument("--ns", type=int, default=0, help="systolic: strips per workgroup")
     ap.add_argument("--nc", type=int, default=0, help="systolic: consumer waves per strip")
+    ap.add_argument("--p8", action="store_true", help="compact predecessor matrix: int8 P (sw_fill_device_ex), 5 or 9 B/cell")
     ap.add_argument("--placement-trials", type=int, default=12,
                     help="pair mode: candidate H/P allocations tried before the timed region (1 = take the first)")
     ap.add_argument("--store-policy", type=int, default=0, help="systolic H/P stores: 0 auto, 1 write-back, 2 streaming")
@@ -176,9 +177,10 @@ def main():
     # allocations by trial fills; the timed steps below then all run on the chosen pair.
     placement_ms = None
     if args.placement_trials > 1:
-        out, placement_ms = eng.alloc_tuned(d_a, d_b, cols, rows, torch.int64 if args.h64 else torch.int32, trials=args.placement_trials)
+        out, placement_ms = eng.alloc_tuned(d_a, d_b, cols, rows, torch.int64 if args.h64 else torch.int32, trials=args.placement_trials,
+                                            p_dtype=torch.int8 if args.p8 else None)
     else:
-        out = eng.alloc(cols, rows, torch.int64 if args.h64 else torch.int32)
+        out = eng.alloc(cols, rows, torch.int64 if args.h64 else torch.int32, torch.int8 if args.p8 else None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -222,7 +224,7 @@ def main():
         except Exception:
             pass
         cells = cols * rows
-        bytes_per_cell = 12 if args.h64 else 8       # mandatory H + P output only
+        bytes_per_cell = (8 if args.h64 else 4) + (1 if args.p8 else 4)   # mandatory H + P output only
         avg_ms = sum(kern_ms) / len(kern_ms)
         achieved = bytes_per_cell * cells / (avg_ms * 1e-3) / 1e9
         line = {
@@ -231,7 +233,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64" if args.h64 else "int32", "data": "synthetic",
             "config": {"workload": f"{cols}x{rows} random DNA pair (reference generator, seed 1+rank), linear gap 3/-3/-2, "
-                                   f"{'int64' if args.h64 else 'int32'} H + int32 P written to HBM, arg-max tracked",
+                                   f"{'int64' if args.h64 else 'int32'} H + {'int8' if args.p8 else 'int32'} P written to HBM, arg-max tracked",
                        "per_gpu": "one independent pair per GPU", "max_pos": res["max_pos"], "max_score": res["max_score"],
                        "grid": eng.get_option("last_grid"), "strips": eng.get_option("last_strips"),
                        "placement_trials_ms": placement_ms},

@@ -87,6 +87,13 @@ int sw_fill_device(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, 
                    const sw_scores* scores, void* d_H, int h_elem_bytes, int32_t* d_P,
                    const int32_t* d_top, sw_result* d_result, void* stream);
 
+/* Same with a compact predecessor matrix: p_elem_bytes 4 -> d_P is int32_t* (identical to
+ * sw_fill_device), 1 -> d_P is int8_t* holding the same codes (0..3; -1..-3 after a traceback), a quarter of
+ * the P traffic and footprint.  Systolic engine only. */
+int sw_fill_device_ex(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, int64_t rows,
+                      const sw_scores* scores, void* d_H, int h_elem_bytes, void* d_P, int p_elem_bytes,
+                      const int32_t* d_top, sw_result* d_result, void* stream);
+
 /* Tile of a bigger matrix (multi-GPU row bands x column chunks).  d_H / d_P point at the
  * tile's corner cell (row above / column left of its first cell) inside matrices of row stride
  * `row_stride` elements; d_top: cols+1 H values of the row above (NULL = zeros), d_left: rows+1 H values
@@ -119,12 +126,18 @@ int sw_traceback_device(sw_ctx* ctx, int32_t* d_P, int64_t cols, int64_t rows, i
                         int64_t* d_path, int64_t path_cap, sw_result* d_result, void* stream);
 int sw_traceback_host(int32_t* P, int64_t cols, int64_t rows, int64_t max_pos,
                       int64_t* path, int64_t path_cap, int64_t* path_len);
+/* the same on an int32 (p_elem_bytes 4) or compact int8 (1) predecessor matrix */
+int sw_traceback_device_ex(sw_ctx* ctx, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos,
+                           int64_t* d_path, int64_t path_cap, sw_result* d_result, void* stream);
+int sw_traceback_host_ex(void* P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos,
+                         int64_t* path, int64_t path_cap, int64_t* path_len);
 
 /* ---- verification helpers (not on the timed path) ------------------------------------------
  * Position-weighted row checksums of a device matrix with (rows1 x m) elements:
  *   cs[i] = sum_j (uint64)(uint32)X[i][j] * ((j+1) * 0x9E3779B97F4A7C15)  (mod 2^64)
- * elem_bytes 4 or 8 (8: low 32 bits are summed and the high half must be the sign extension,
- * otherwise cs[i] is forced to ~0). d_cs: rows1 uint64 on the device. */
+ * elem_bytes 1, 4 or 8 (1: int8 values are sign-extended first, so a compact P checksums like its int32
+ * widening; 8: low 32 bits are summed and the high half must be the sign extension, otherwise cs[i] is
+ * forced to ~0). d_cs: rows1 uint64 on the device. */
 int sw_row_checksums_device(sw_ctx* ctx, const void* d_X, int elem_bytes, int64_t rows1, int64_t m,
                             uint64_t* d_cs, void* stream);
 

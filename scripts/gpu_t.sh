@@ -1,13 +1,9 @@
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 || exit 1
-for i in 1 2 3; do
-for v in base prev; do
-  if [ $v = base ]; then unset SWHIP_LIBRARY; else export SWHIP_LIBRARY=$PWD/build/libswhip_$v.so; fi
-  echo -n "$v: "; python bench.py --no-cpu --steps 20 --warmup 3 2>&1 | python3 -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); t=d['config']['placement_trials_ms']; print('%.1f GCUPS  [%s]'%(d['value'],' '.join('%.3f'%x for x in t)))
-"
-done; done
-unset SWHIP_LIBRARY
-python scripts/strip_times.py 16384 16384 0 2 4 2>&1 | grep -E "^   0:|hops|last end|strips mean"
+run() { echo -n "$*: "; python bench.py --no-cpu "$@" 2>&1 | grep -o '"value": [0-9.]*\|"frac": [0-9.]*' | tr '\n' ' '; echo; }
+run --steps 20 --warmup 3
+run --steps 20 --warmup 3 --p8
+run --cols 32768 --rows 32768 --steps 5 --warmup 1 --placement-trials 2
+run --cols 32768 --rows 32768 --steps 5 --warmup 1 --placement-trials 2 --p8
+run --cols 65536 --rows 65536 --steps 3 --warmup 1 --placement-trials 1
+run --cols 65536 --rows 65536 --steps 3 --warmup 1 --placement-trials 1 --p8
+run --cols 65536 --rows 65536 --steps 3 --warmup 1 --placement-trials 1 --h64
+run --cols 65536 --rows 65536 --steps 3 --warmup 1 --placement-trials 1 --h64 --p8

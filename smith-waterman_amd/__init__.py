@@ -57,6 +57,9 @@ ABI = {
     "sw_fill_host": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result)]),
     "sw_traceback_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "sw_traceback_host": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
+    "sw_traceback_host_ex": (_i32, [_vp, _i32, _i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
+    "sw_traceback_device_ex": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "sw_fill_device_ex": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sw_row_checksums_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
     "sw_device_malloc": (_i32, [_vp, _sz, ctypes.POINTER(_vp)]),
     "sw_device_free": (_i32, [_vp, _vp]),
@@ -123,12 +126,13 @@ def first_diag_element(i: int, m: int, n: int):
 
 
 def traceback_host(P: np.ndarray, max_pos: int):
-    """backtrack() on a host int32 P (modified in place). Returns the visited linear indices."""
+    """backtrack() on a host int32 (or compact int8) P, modified in place. Returns the visited linear indices."""
     rows1, m = P.shape
-    assert P.dtype == np.int32 and P.flags.c_contiguous
+    assert P.dtype in (np.int32, np.int8) and P.flags.c_contiguous
     path = np.zeros(rows1 + m + 2, np.int64)
     n = _i64()
-    _check(lib().sw_traceback_host(P.ctypes.data, m - 1, rows1 - 1, int(max_pos), path.ctypes.data, len(path), ctypes.byref(n)))
+    _check(lib().sw_traceback_host_ex(P.ctypes.data, P.dtype.itemsize, m - 1, rows1 - 1, int(max_pos), path.ctypes.data, len(path),
+                                      ctypes.byref(n)))
     return path[: n.value].copy()
 
 
@@ -200,13 +204,18 @@ class Engine:
             d[: len(s)] = t.from_numpy(s.copy())
         return d, len(s)
 
-    def alloc(self, cols: int, rows: int, h_dtype=None):
+    def alloc(self, cols: int, rows: int, h_dtype=None, p_dtype=None):
+        """Output buffers: H int32|int64, P int32 (the reference layout) or int8 (compact P, same codes)."""
         t = self.torch
         h_dtype = h_dtype or t.int32
+        p_dtype = p_dtype or t.int32
+        assert p_dtype in (t.int32, t.int8)
         dev = f"cuda:{self.device}"
         H = t.empty((rows + 1, cols + 1), dtype=h_dtype, device=dev)
         n = (rows + 1) * (cols + 1)
-        if h_dtype == t.int32 and n * 4 >= (64 << 20):
+        if p_dtype == t.int8:
+            P = t.empty((rows + 1, cols + 1), dtype=t.int8, device=dev)
+        elif h_dtype == t.int32 and n * 4 >= (64 << 20):
             # H[r][c] and P[r][c] are stored by the same wave within a fraction of a microsecond.  When the two
             # addresses agree in their low 22 bits they land in the same DRAM bank (measured on MI355X: fill time
             # periodic in (P - H) mod 4 MiB, worst at 0, best at 2 MiB, 5-9 % apart), so P is placed 2 MiB out of phase.
@@ -219,7 +228,7 @@ class Engine:
         res = t.zeros(3, dtype=t.int64, device=dev)
         return Fill(H, P, res, cols, rows)
 
-    def alloc_tuned(self, d_a, d_b, cols: int, rows: int, h_dtype=None, trials: int = 4, fills: int = 3):
+    def alloc_tuned(self, d_a, d_b, cols: int, rows: int, h_dtype=None, trials: int = 4, fills: int = 3, p_dtype=None):
         """alloc() with placement tuning: the fill's speed depends on where the driver put H and P in
         physical memory (measured on MI355X: two modes ~15 % apart per allocation, same virtual addresses
         or not).  Allocate up to `trials` candidate pairs of buffers, time `fills` fills into each and keep
@@ -228,7 +237,7 @@ class Engine:
         best, best_ms, seen, held = None, float("inf"), [], []
         for _ in range(max(1, trials)):
             try:
-                cand = self.alloc(cols, rows, h_dtype)
+                cand = self.alloc(cols, rows, h_dtype, p_dtype)
             except RuntimeError:      # out of HBM: stay with what we have
                 break
             self.fill_into(cand, d_a, d_b)
@@ -255,15 +264,15 @@ class Engine:
         t = self.torch
         sc = _Scores(*scores)
         hb = 8 if out.H.dtype == t.int64 else 4
-        _check(lib().sw_fill_device(self._h, d_a.data_ptr(), out.cols, d_b.data_ptr(), out.rows, ctypes.byref(sc),
-                                    out.H.data_ptr(), hb, out.P.data_ptr(),
-                                    top.data_ptr() if top is not None else None, out.res.data_ptr(), self._stream()))
+        _check(lib().sw_fill_device_ex(self._h, d_a.data_ptr(), out.cols, d_b.data_ptr(), out.rows, ctypes.byref(sc),
+                                       out.H.data_ptr(), hb, out.P.data_ptr(), out.P.element_size(),
+                                       top.data_ptr() if top is not None else None, out.res.data_ptr(), self._stream()))
         return out
 
-    def fill(self, a, b, scores=DEFAULT_SCORES, h_dtype=None, top=None) -> Fill:
+    def fill(self, a, b, scores=DEFAULT_SCORES, h_dtype=None, top=None, p_dtype=None) -> Fill:
         d_a, cols = self.to_device(a)
         d_b, rows = self.to_device(b)
-        out = self.alloc(cols, rows, h_dtype)
+        out = self.alloc(cols, rows, h_dtype, p_dtype)
         if top is not None:
             top = self.torch.as_tensor(np.ascontiguousarray(top, np.int32)).to(f"cuda:{self.device}")
         self.fill_into(out, d_a, d_b, scores, top)
@@ -321,8 +330,8 @@ class Engine:
             max_pos = out.result()["max_pos"]
         cap = out.cols + out.rows + 2
         path = t.zeros(cap if want_path else 1, dtype=t.int64, device=out.P.device)
-        _check(lib().sw_traceback_device(self._h, out.P.data_ptr(), out.cols, out.rows, int(max_pos),
-                                         path.data_ptr() if want_path else None, cap, out.res.data_ptr(), self._stream()))
+        _check(lib().sw_traceback_device_ex(self._h, out.P.data_ptr(), out.P.element_size(), out.cols, out.rows, int(max_pos),
+                                            path.data_ptr() if want_path else None, cap, out.res.data_ptr(), self._stream()))
         self.synchronize()
         n = int(out.res[2].item())
         return path[:n].cpu().numpy() if want_path else n

@@ -135,6 +135,7 @@ struct FillJob {
     const int32_t* d_top; const int32_t* d_left; int32_t* d_right;
     int64_t npairs; int64_t a_pstride, b_pstride, hp_pstride;
     unsigned long long* d_keys;   // npairs packed arg-max keys (device)
+    int p_elem_bytes = 4;         // 4: int32 P (reference layout); 1: compact int8 P
 };
 
 static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStream_t stream) {
@@ -174,6 +175,8 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
     p.xcd_order = (int)c->opt_xcd_order;
     p.dbg = (unsigned long long*)(uintptr_t)c->opt_dbg_ptr;
     p.npairs = (int)j.npairs; p.store_hp = j.d_H ? 1 : 0;
+    p.p_bytes = j.p_elem_bytes;
+    if (j.p_elem_bytes == 1 && (!systolic || j.npairs != 1)) { set_err("compact (int8) P needs the systolic engine and a single pair"); return SW_EINVAL; }
     p.a_pstride = j.a_pstride; p.b_pstride = j.b_pstride; p.hp_pstride = j.hp_pstride;
     p.edge_pstride = S * (rows + 1);
     const unsigned char* ua = (const unsigned char*)j.d_a;
@@ -231,12 +234,13 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
     return SW_OK;
 }
 
-int sw_fill_tile_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
-                        void* d_H, int h_elem_bytes, int32_t* d_P, int64_t row_stride, const int32_t* d_top,
-                        const int32_t* d_left, int32_t* d_right, sw_result* d_result, void* stream_) {
+static int fill_tile_impl(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
+                          void* d_H, int h_elem_bytes, void* d_P, int p_elem_bytes, int64_t row_stride, const int32_t* d_top,
+                          const int32_t* d_left, int32_t* d_right, sw_result* d_result, void* stream_) {
     static const sw_scores kDefault = {3, -3, -2};  // serial_smithW.c:59-61
     const sw_scores* sc = scores ? scores : &kDefault;
-    if (!c || !d_H || !d_P || !d_result || (h_elem_bytes != 4 && h_elem_bytes != 8) || row_stride < cols + 1) {
+    if (!c || !d_H || !d_P || !d_result || (h_elem_bytes != 4 && h_elem_bytes != 8) || (p_elem_bytes != 4 && p_elem_bytes != 1) ||
+        row_stride < cols + 1) {
         set_err("sw_fill_tile_device: bad argument");
         return SW_EINVAL;
     }
@@ -250,11 +254,12 @@ int sw_fill_tile_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_
         if (row_stride != cols + 1 || d_left || d_right) { set_err("empty tiles are not supported"); return SW_EINVAL; }
         const int64_t M = cols + 1;
         HIP_TRY(hipMemsetAsync(d_H, 0, (size_t)(M * (rows + 1)) * h_elem_bytes, stream));
-        HIP_TRY(hipMemsetAsync(d_P, 0, (size_t)(M * (rows + 1)) * 4, stream));
+        HIP_TRY(hipMemsetAsync(d_P, 0, (size_t)(M * (rows + 1)) * p_elem_bytes, stream));
         if (d_top && h_elem_bytes == 4) HIP_TRY(hipMemcpyAsync(d_H, d_top, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
         if (d_top && h_elem_bytes == 8) { set_err("top halo with an empty int64 band is unsupported"); return SW_EINVAL; }
     } else {
-        FillJob j = {d_a, cols, d_b, rows, d_H, h_elem_bytes, d_P, row_stride, d_top, d_left, d_right, 1, 0, 0, 0, c->d_key};
+        FillJob j = {d_a, cols, d_b, rows, d_H, h_elem_bytes, (int32_t*)d_P, row_stride, d_top, d_left, d_right, 1, 0, 0, 0, c->d_key};
+        j.p_elem_bytes = p_elem_bytes;
         if (int rc = launch_fill(c, sc, j, stream)) return rc;
     }
     hipLaunchKernelGGL(swk::sw_finalize, dim3(1), dim3(64), 0, stream, c->d_key, (const unsigned int*)(c->d_key + 1), d_result, 1);
@@ -262,9 +267,22 @@ int sw_fill_tile_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_
     return SW_OK;
 }
 
+int sw_fill_tile_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
+                        void* d_H, int h_elem_bytes, int32_t* d_P, int64_t row_stride, const int32_t* d_top,
+                        const int32_t* d_left, int32_t* d_right, sw_result* d_result, void* stream_) {
+    return fill_tile_impl(c, d_a, cols, d_b, rows, scores, d_H, h_elem_bytes, d_P, 4, row_stride, d_top, d_left, d_right, d_result, stream_);
+}
+
 int sw_fill_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
                    void* d_H, int h_elem_bytes, int32_t* d_P, const int32_t* d_top, sw_result* d_result, void* stream_) {
-    return sw_fill_tile_device(c, d_a, cols, d_b, rows, scores, d_H, h_elem_bytes, d_P, cols + 1, d_top, nullptr, nullptr, d_result, stream_);
+    return fill_tile_impl(c, d_a, cols, d_b, rows, scores, d_H, h_elem_bytes, d_P, 4, cols + 1, d_top, nullptr, nullptr, d_result, stream_);
+}
+
+// compact P: one byte per predecessor code (same values 0..3, -1..-3 after the traceback), SURVEY.md 8f-2
+int sw_fill_device_ex(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
+                      void* d_H, int h_elem_bytes, void* d_P, int p_elem_bytes, const int32_t* d_top, sw_result* d_result,
+                      void* stream_) {
+    return fill_tile_impl(c, d_a, cols, d_b, rows, scores, d_H, h_elem_bytes, d_P, p_elem_bytes, cols + 1, d_top, nullptr, nullptr, d_result, stream_);
 }
 
 // BASELINE config 5: npairs independent cols x rows problems; pair k reads a at d_a + k*a_stride, b at d_b + k*b_stride.
@@ -334,17 +352,26 @@ int sw_fill_host(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t 
     return rc;
 }
 
-int sw_traceback_device(sw_ctx* c, int32_t* d_P, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path,
-                        int64_t path_cap, sw_result* d_result, void* stream_) {
-    if (!c || !d_P || !d_result || cols < 0 || rows < 0 || max_pos < 0 || max_pos >= (cols + 1) * (rows + 1)) {
+int sw_traceback_device_ex(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path,
+                           int64_t path_cap, sw_result* d_result, void* stream_) {
+    if (!c || !d_P || !d_result || cols < 0 || rows < 0 || max_pos < 0 || max_pos >= (cols + 1) * (rows + 1) ||
+        (p_elem_bytes != 4 && p_elem_bytes != 1)) {
         set_err("sw_traceback_device: bad argument");
         return SW_EINVAL;
     }
     HIP_TRY(hipSetDevice(c->device));
-    hipLaunchKernelGGL(swk::sw_traceback, dim3(1), dim3(64), 0, (hipStream_t)stream_, d_P, cols + 1, max_pos, d_path,
-                       d_path ? path_cap : 0, d_result);
+    if (p_elem_bytes == 4)
+        hipLaunchKernelGGL(swk::sw_traceback<int32_t>, dim3(1), dim3(64), 0, (hipStream_t)stream_, (int32_t*)d_P, cols + 1, max_pos, d_path,
+                           d_path ? path_cap : 0, d_result);
+    else
+        hipLaunchKernelGGL(swk::sw_traceback<signed char>, dim3(1), dim3(64), 0, (hipStream_t)stream_, (signed char*)d_P, cols + 1, max_pos,
+                           d_path, d_path ? path_cap : 0, d_result);
     HIP_TRY(hipGetLastError());
     return SW_OK;
+}
+int sw_traceback_device(sw_ctx* c, int32_t* d_P, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path,
+                        int64_t path_cap, sw_result* d_result, void* stream_) {
+    return sw_traceback_device_ex(c, d_P, 4, cols, rows, max_pos, d_path, path_cap, d_result, stream_);
 }
 
 int sw_device_malloc(sw_ctx* c, size_t bytes, void** d_ptr) {
@@ -380,7 +407,7 @@ int sw_synchronize(sw_ctx* c, void* stream_) {
 
 int sw_row_checksums_device(sw_ctx* c, const void* d_X, int elem_bytes, int64_t rows1, int64_t m, uint64_t* d_cs,
                             void* stream_) {
-    if (!c || !d_X || !d_cs || rows1 <= 0 || m <= 0 || (elem_bytes != 4 && elem_bytes != 8) || rows1 > 0x7fffffff) {
+    if (!c || !d_X || !d_cs || rows1 <= 0 || m <= 0 || (elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 1) || rows1 > 0x7fffffff) {
         set_err("sw_row_checksums_device: bad argument");
         return SW_EINVAL;
     }
@@ -389,6 +416,9 @@ int sw_row_checksums_device(sw_ctx* c, const void* d_X, int elem_bytes, int64_t 
     if (elem_bytes == 4)
         hipLaunchKernelGGL((swk::sw_row_checksums<int32_t>), dim3((unsigned)rows1), dim3(256), 0, stream,
                            (const int32_t*)d_X, m, (unsigned long long*)d_cs);
+    else if (elem_bytes == 1)
+        hipLaunchKernelGGL((swk::sw_row_checksums<signed char>), dim3((unsigned)rows1), dim3(256), 0, stream,
+                           (const signed char*)d_X, m, (unsigned long long*)d_cs);
     else
         hipLaunchKernelGGL((swk::sw_row_checksums<int64_t>), dim3((unsigned)rows1), dim3(256), 0, stream,
                            (const int64_t*)d_X, m, (unsigned long long*)d_cs);

@@ -50,6 +50,18 @@ inline char letter(int v) {  // serial_smithW.c:339-346
 }
 }  // namespace swh
 
+template <typename PT>
+static int64_t traceback_t(PT* P, int64_t m, int64_t max_pos, int64_t* path, int64_t path_cap) {  // serial_smithW.c:262-277
+    int64_t len = 0, pos = max_pos;
+    for (int pr = P[pos]; pr > 0; pr = P[pos]) {
+        P[pos] = (PT)(pr * SW_PATH);
+        if (path && len < path_cap) path[len] = pos;
+        ++len;
+        pos -= (pr == SW_DIAGONAL) ? m + 1 : (pr == SW_UP) ? m : 1;
+    }
+    return len;
+}
+
 extern "C" {
 
 const char* sw_last_error(void) { return swh::g_err.c_str(); }
@@ -78,22 +90,21 @@ void sw_first_diag_element(int64_t i, int64_t m, int64_t n, int64_t* si, int64_t
     if (sj) *sj = left_edge ? 1 : i - n + 2;
 }
 
-int sw_traceback_host(int32_t* P, int64_t cols, int64_t rows, int64_t max_pos, int64_t* path,
-                      int64_t path_cap, int64_t* path_len) {  // serial_smithW.c:262-277
+int sw_traceback_host_ex(void* P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos, int64_t* path,
+                         int64_t path_cap, int64_t* path_len) {
     const int64_t m = cols + 1;
-    if (!P || cols < 0 || rows < 0 || max_pos < 0 || max_pos >= m * (rows + 1)) {
+    if (!P || cols < 0 || rows < 0 || max_pos < 0 || max_pos >= m * (rows + 1) || (p_elem_bytes != 4 && p_elem_bytes != 1)) {
         swh::set_err("sw_traceback_host: bad argument");
         return SW_EINVAL;
     }
-    int64_t len = 0, pos = max_pos;
-    for (int pr = P[pos]; pr > 0; pr = P[pos]) {
-        P[pos] = pr * SW_PATH;
-        if (path && len < path_cap) path[len] = pos;
-        ++len;
-        pos -= (pr == SW_DIAGONAL) ? m + 1 : (pr == SW_UP) ? m : 1;
-    }
+    const int64_t len = p_elem_bytes == 4 ? traceback_t((int32_t*)P, m, max_pos, path, path_cap)
+                                          : traceback_t((signed char*)P, m, max_pos, path, path_cap);
     if (path_len) *path_len = len;
     return SW_OK;
+}
+int sw_traceback_host(int32_t* P, int64_t cols, int64_t rows, int64_t max_pos, int64_t* path,
+                      int64_t path_cap, int64_t* path_len) {
+    return sw_traceback_host_ex(P, 4, cols, rows, max_pos, path, path_cap, path_len);
 }
 
 // FASTA reader: the step before the path when the input is a real sequence instead of generate()

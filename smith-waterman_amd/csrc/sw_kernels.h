@@ -30,6 +30,7 @@ struct FillParams {
     int bfront;                // systolic: index of b[0] inside bpad / bpad16
     const unsigned short* bpad16;
     unsigned long long* dbg;   // optional: per strip {start, end} s_memrealtime stamps of its producer (experiments)
+    int p_bytes;               // bytes per P element: 4 (reference layout) or 1 (compact, systolic engine only)
     int store_nt;              // systolic: streaming (nt) H/P stores
     int xcd_order;             // systolic: neighbouring strip groups on one XCD
     int pace_ps;               // systolic: strip 0 releases one row per pace_ps picoseconds (0 = unpaced)
@@ -43,7 +44,8 @@ template <typename HT, int NS, int NC>
 __global__ void sw_systolic(const unsigned char* a, const unsigned char* b, const unsigned char* bpad, FillParams p);
 __global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, int64_t b_pstride, unsigned char* bpad, unsigned short* bpad16, int64_t per);
 __global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res, int n);
-__global__ void sw_traceback(int32_t* P, int64_t M, int64_t maxPos, int64_t* path, int64_t cap, sw_result* res);
+template <typename PT>
+__global__ void sw_traceback(PT* P, int64_t M, int64_t maxPos, int64_t* path, int64_t cap, sw_result* res);
 template <typename T> __global__ void sw_row_checksums(const T* X, int64_t m, unsigned long long* cs);
 
 }  // namespace swk

@@ -272,14 +272,15 @@ __global__ void sw_finalize(const unsigned long long* key, const unsigned int* a
 }
 
 // backtrack(), serial_smithW.c:262-277: one lane walks P from maxPos and negates the path.
-__global__ void sw_traceback(int32_t* __restrict__ P, int64_t M, int64_t maxPos, int64_t* __restrict__ path,
+template <typename PT>
+__global__ void sw_traceback(PT* __restrict__ P, int64_t M, int64_t maxPos, int64_t* __restrict__ path,
                              int64_t cap, sw_result* res) {
     if (threadIdx.x | blockIdx.x) return;
     int64_t len = 0, pos = maxPos;
     int pr = P[pos];
     while (pr > 0) {
         const int64_t pred = (pr == 3) ? pos - M - 1 : (pr == 1) ? pos - M : pos - 1;
-        P[pos] = -pr;
+        P[pos] = (PT)-pr;
         if (path && len < cap) path[len] = pos;
         ++len;
         pos = pred;
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(256) sw_row_checksums(const T* __restrict__ X,
     for (int64_t j = threadIdx.x; j < m; j += blockDim.x) {
         const T v = row[j];
         if (sizeof(T) == 8 && (int64_t)v != (int64_t)(int32_t)v) bad = true;
-        acc += (u64)(uint32_t)v * ((u64)(j + 1) * 0x9E3779B97F4A7C15ull);
+        acc += (u64)(uint32_t)(int32_t)v * ((u64)(j + 1) * 0x9E3779B97F4A7C15ull);
     }
     __shared__ u64 red[256];
     __shared__ int anybad;
@@ -315,5 +316,8 @@ __global__ void __launch_bounds__(256) sw_row_checksums(const T* __restrict__ X,
 }
 template __global__ void sw_row_checksums<int32_t>(const int32_t*, int64_t, u64*);
 template __global__ void sw_row_checksums<int64_t>(const int64_t*, int64_t, u64*);
+template __global__ void sw_row_checksums<signed char>(const signed char*, int64_t, u64*);
+template __global__ void sw_traceback<int32_t>(int32_t*, int64_t, int64_t, int64_t*, int64_t, sw_result*);
+template __global__ void sw_traceback<signed char>(signed char*, int64_t, int64_t, int64_t*, int64_t, sw_result*);
 
 }  // namespace swk

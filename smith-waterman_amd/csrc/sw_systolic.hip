@@ -482,8 +482,8 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
 #define CB_H(POL, K, G)                                                                            \
     "v_add_u32 %[z], %[z], %[ngap]\n\t"                                                      \
     "v_sub_u32 v" #K ", %[" G "], %[z]\n\t"                                                   \
-    "buffer_store_dword v" #K ", %[voff], %[rH], s80 offen" CB_POLH(POL) "\n\t"                              \
-    "s_add_u32 s80, s80, %[stride]\n\t"
+    "buffer_store_dword v" #K ", %[voffH], %[rH], s81 offen" CB_POLH(POL) "\n\t"                             \
+    "s_add_u32 s81, s81, %[strideH]\n\t"
 // int64 H: the score is never negative, so the high dword is a zero register paired with each H register
 #define CB_H64(POL, K, K1, G)                                                                 \
     "v_add_u32 %[z], %[z], %[ngap]\n\t"                                                      \
@@ -494,14 +494,14 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
 #define CB_PRED(G, UP, DD, M1, M3)                                                            \
     "v_cmp_eq_u32_e64 " M1 ", %[" UP "], %[" G "]\n\t"                                       \
     "v_cmp_eq_u32_e64 " M3 ", " DD ", %[" G "]\n\t"
-#define CB_SEL(POL, HK, PI, M1, M3)                                                                \
+#define CB_SEL(POL, PST, HK, PI, M1, M3)                                                                \
     "v_cmp_eq_u32_e32 vcc, 0, " HK "\n\t"                                                    \
     "v_cndmask_b32_e64 " PI ", 2, 1, " M1 "\n\t"                                             \
     "v_cndmask_b32_e64 " PI ", " PI ", 3, " M3 "\n\t"                                        \
     "v_cndmask_b32_e64 " PI ", " PI ", 0, vcc\n\t"                                           \
-    "buffer_store_dword " PI ", %[voff], %[rP], s80 offen" CB_POLP(POL) "\n\t"                               \
+    PST " " PI ", %[voff], %[rP], s80 offen" CB_POLP(POL) "\n\t"                                             \
     "s_add_u32 s80, s80, %[stride]\n\t"
-#define CB_GROUP(POL, CH, U, G0, G1, G2, G3, H0, H1, H2, H3)                                       \
+#define CB_GROUP(POL, PST, CH, U, G0, G1, G2, G3, H0, H1, H2, H3)                                       \
     "v_cmp_eq_u32_sdwa s[60:61], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_0\n\t"            \
     "v_cmp_eq_u32_sdwa s[62:63], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_1\n\t"            \
     "v_cmp_eq_u32_sdwa s[64:65], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_2\n\t"            \
@@ -516,17 +516,17 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
     "v_add_u32_dpp v123, %[" G2 "], v119 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
     CB_PRED(G0, U, "v120", "s[60:61]", "s[62:63]")                                            \
     CB_PRED(G1, G0, "v121", "s[64:65]", "s[66:67]")                                           \
-    CB_SEL(POL, H0, "v124", "s[60:61]", "s[62:63]")                                                \
+    CB_SEL(POL, PST, H0, "v124", "s[60:61]", "s[62:63]")                                                \
     CB_PRED(G2, G1, "v122", "s[68:69]", "s[70:71]")                                           \
-    CB_SEL(POL, H1, "v125", "s[64:65]", "s[66:67]")                                                \
+    CB_SEL(POL, PST, H1, "v125", "s[64:65]", "s[66:67]")                                                \
     CB_PRED(G3, G2, "v123", "s[72:73]", "s[74:75]")                                           \
-    CB_SEL(POL, H2, "v126", "s[68:69]", "s[70:71]")                                                \
-    CB_SEL(POL, H3, "v127", "s[72:73]", "s[74:75]")
+    CB_SEL(POL, PST, H2, "v126", "s[68:69]", "s[70:71]")                                                \
+    CB_SEL(POL, PST, H3, "v127", "s[72:73]", "s[74:75]")
 typedef int sw_i32x4 __attribute__((ext_vector_type(4)));
-#define CB_ASM(POL) \
+#define CB_ASM(POL, PST) \
     asm volatile( \
         "s_load_dwordx4 s[76:79], %[cptr], 0x0\n\t" \
-        "s_mov_b32 s80, 0\n\t" \
+        "s_mov_b32 s81, 0\n\t" \
         CB_H(POL, 100, "g1") CB_H(POL, 101, "g2") CB_H(POL, 102, "g3") CB_H(POL, 103, "g4") CB_H(POL, 104, "g5") CB_H(POL, 105, "g6") CB_H(POL, 106, "g7") CB_H(POL, 107, "g8") \
         CB_H(POL, 108, "g9") CB_H(POL, 109, "g10") CB_H(POL, 110, "g11") CB_H(POL, 111, "g12") CB_H(POL, 112, "g13") CB_H(POL, 113, "g14") CB_H(POL, 114, "g15") CB_H(POL, 115, "g16") \
         "v_max3_i32 %[bm], %[bm], v100, v101\n\t" \
@@ -539,28 +539,20 @@ typedef int sw_i32x4 __attribute__((ext_vector_type(4)));
         "v_max3_i32 %[bm], %[bm], v116, v119\n\t" \
         "s_mov_b32 s80, 0\n\t" \
         "s_waitcnt lgkmcnt(0)\n\t" \
-        CB_GROUP(POL, "s76", "g0", "g1", "g2", "g3", "g4", "v100", "v101", "v102", "v103") \
-        CB_GROUP(POL, "s77", "g4", "g5", "g6", "g7", "g8", "v104", "v105", "v106", "v107") \
-        CB_GROUP(POL, "s78", "g8", "g9", "g10", "g11", "g12", "v108", "v109", "v110", "v111") \
-        CB_GROUP(POL, "s79", "g12", "g13", "g14", "g15", "g16", "v112", "v113", "v114", "v115") \
+        CB_GROUP(POL, PST, "s76", "g0", "g1", "g2", "g3", "g4", "v100", "v101", "v102", "v103") \
+        CB_GROUP(POL, PST, "s77", "g4", "g5", "g6", "g7", "g8", "v104", "v105", "v106", "v107") \
+        CB_GROUP(POL, PST, "s78", "g8", "g9", "g10", "g11", "g12", "v108", "v109", "v110", "v111") \
+        CB_GROUP(POL, PST, "s79", "g12", "g13", "g14", "g15", "g16", "v112", "v113", "v114", "v115") \
         : [z] "+v"(z), [bm] "+v"(blkmax) \
         : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]), [g7] "v"(g[7]), \
           [g8] "v"(g[8]), [g9] "v"(g[9]), [g10] "v"(g[10]), [g11] "v"(g[11]), [g12] "v"(g[12]), [g13] "v"(g[13]), [g14] "v"(g[14]), \
           [g15] "v"(g[15]), [g16] "v"(g[16]), [a] "v"(a_l), [mm] "v"(mm_v), [xm] "v"(xm_v), [ngap] "v"(ngap_v), [voff] "v"(voff), \
-          [rH] "s"(rH), [rP] "s"(rP), [stride] "s"(stride), [cptr] "s"(chars) \
+          [voffH] "v"(voffH), [rH] "s"(rH), [rP] "s"(rP), [stride] "s"(stride), [strideH] "s"(strideH), [cptr] "s"(chars) \
         : "vcc", "scc", "memory", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", \
-          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", \
+          "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", \
           "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", \
           "v124", "v125", "v126", "v127")
-// NT: streaming (nt) stores -- H and P are written once and never re-read by the fill; which policy is faster
-// depends on the problem size (measured: nt wins at 16384^2, plain write-back at 32768^2)
-template <bool NT>
-__device__ __forceinline__ void consumer_block16(const u32 (&g)[SY_U + 1], u32& z, u32& blkmax, u32 a_l, u32 mm_v, u32 xm_v, u32 ngap_v,
-                                                 u32 voff, sw_i32x4 rH, sw_i32x4 rP, u32 stride, const unsigned char* chars) {
-    if constexpr (NT) { CB_ASM(" nt"); } else { CB_ASM(""); }
-}
-
-#define CB_ASM64(POL) \
+#define CB_ASM64(POL, PST) \
     asm volatile( \
         "s_load_dwordx4 s[76:79], %[cptr], 0x0\n\t" \
         "s_mov_b32 s81, 0\n\t" \
@@ -578,10 +570,10 @@ __device__ __forceinline__ void consumer_block16(const u32 (&g)[SY_U + 1], u32& 
         "v_max3_i32 %[bm], %[bm], v116, v119\n\t" \
         "s_mov_b32 s80, 0\n\t" \
         "s_waitcnt lgkmcnt(0)\n\t" \
-        CB_GROUP(POL, "s76", "g0", "g1", "g2", "g3", "g4", "v64", "v66", "v68", "v70") \
-        CB_GROUP(POL, "s77", "g4", "g5", "g6", "g7", "g8", "v72", "v74", "v76", "v78") \
-        CB_GROUP(POL, "s78", "g8", "g9", "g10", "g11", "g12", "v80", "v82", "v84", "v86") \
-        CB_GROUP(POL, "s79", "g12", "g13", "g14", "g15", "g16", "v88", "v90", "v92", "v94") \
+        CB_GROUP(POL, PST, "s76", "g0", "g1", "g2", "g3", "g4", "v64", "v66", "v68", "v70") \
+        CB_GROUP(POL, PST, "s77", "g4", "g5", "g6", "g7", "g8", "v72", "v74", "v76", "v78") \
+        CB_GROUP(POL, PST, "s78", "g8", "g9", "g10", "g11", "g12", "v80", "v82", "v84", "v86") \
+        CB_GROUP(POL, PST, "s79", "g12", "g13", "g14", "g15", "g16", "v88", "v90", "v92", "v94") \
         : [z] "+v"(z), [bm] "+v"(blkmax) \
         : [g0] "v"(g[0]), [g1] "v"(g[1]), [g2] "v"(g[2]), [g3] "v"(g[3]), [g4] "v"(g[4]), [g5] "v"(g[5]), [g6] "v"(g[6]), [g7] "v"(g[7]), \
           [g8] "v"(g[8]), [g9] "v"(g[9]), [g10] "v"(g[10]), [g11] "v"(g[11]), [g12] "v"(g[12]), [g13] "v"(g[13]), [g14] "v"(g[14]), \
@@ -591,11 +583,26 @@ __device__ __forceinline__ void consumer_block16(const u32 (&g)[SY_U + 1], u32& 
           "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", \
           "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", \
           "v92", "v93", "v94", "v95", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
-template <bool NT>
+// NT: streaming (nt) stores -- H and P are written once and never re-read by the fill; which policy is faster
+// depends on the problem size (measured: nt wins at 16384^2, plain write-back at 32768^2).
+// P8: the predecessor matrix as one byte per cell (compact P) instead of the reference's int32.
+template <bool NT, bool P8>
+__device__ __forceinline__ void consumer_block16(const u32 (&g)[SY_U + 1], u32& z, u32& blkmax, u32 a_l, u32 mm_v, u32 xm_v, u32 ngap_v,
+                                                 u32 voff, u32 voffH, sw_i32x4 rH, sw_i32x4 rP, u32 stride, u32 strideH,
+                                                 const unsigned char* chars) {
+    if constexpr (NT && P8) { CB_ASM(" nt", "buffer_store_byte"); }
+    else if constexpr (NT) { CB_ASM(" nt", "buffer_store_dword"); }
+    else if constexpr (P8) { CB_ASM("", "buffer_store_byte"); }
+    else { CB_ASM("", "buffer_store_dword"); }
+}
+template <bool NT, bool P8>
 __device__ __forceinline__ void consumer_block16_h64(const u32 (&g)[SY_U + 1], u32& z, u32& blkmax, u32 a_l, u32 mm_v, u32 xm_v,
                                                      u32 ngap_v, u32 voff, u32 voffH, sw_i32x4 rH, sw_i32x4 rP, u32 stride, u32 strideH,
                                                      const unsigned char* chars) {
-    if constexpr (NT) { CB_ASM64(" nt"); } else { CB_ASM64(""); }
+    if constexpr (NT && P8) { CB_ASM64(" nt", "buffer_store_byte"); }
+    else if constexpr (NT) { CB_ASM64(" nt", "buffer_store_dword"); }
+    else if constexpr (P8) { CB_ASM64("", "buffer_store_byte"); }
+    else { CB_ASM64("", "buffer_store_dword"); }
 }
 
 template <typename HT, int NS, int NC>
@@ -807,7 +814,8 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 const bool right_strip = last_strip && p.right != nullptr;   // this strip also returns the tile's right edge column
                 const bool right_lane = right_strip && lane == lc;
                 const u32 voffH = store_ok ? j * (u32)sizeof(HT) : SY_OOB;
-                const u32 voffP = store_ok ? j * 4u : SY_OOB;
+                const bool p8 = (p.p_bytes == 1);                 // compact predecessor matrix: one byte per cell
+                const u32 voffP = store_ok ? j * (p8 ? 1u : 4u) : SY_OOB;
                 const int a_l = (lane >= 1 && jvalid) ? (int)seq_a[j - 1] : SY_ASENT;
                 const int cz = ngap * (int)j;
                 const int G0v = jvalid ? (p.top ? p.top[j] : 0) + cz : 0;
@@ -815,7 +823,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 int32_t* P = p.P;
                 if (ci == 0 && store_ok) {  // row 0: the halo row itself (P of a row owned by the tile above is left alone)
                     H[j] = (HT)(p.top ? p.top[j] : 0);
-                    if (!p.top) P[j] = 0;
+                    if (!p.top) { if (p8) ((signed char*)P)[j] = 0; else P[j] = 0; }
                 }
                 if (ci == 0 && right_lane) p.right[0] = p.top ? p.top[j] : 0;
                 int bestv = 0, bestblk = 0;   // arg-max: best value and the first of MY blocks that reached it
@@ -853,8 +861,9 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                     snap_prod = lds_load(&lds.prod_u[ls]);  // looked at again one block later
                     if (r0 == 1) gv[0] = (u32)G0v;
                     const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)(H + (int64_t)r0 * M), 0, 0x7FFFFF00, 0x00020000);
-                    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(P + (int64_t)r0 * M), 0, 0x7FFFFF00, 0x00020000);
-                    const u32 rowH = (u32)(M * (int64_t)sizeof(HT)), rowP = (u32)(M * 4);
+                    char* const Prow = p8 ? (char*)P + (int64_t)r0 * M : (char*)(P + (int64_t)r0 * M);
+                    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)Prow, 0, 0x7FFFFF00, 0x00020000);
+                    const u32 rowH = (u32)(M * (int64_t)sizeof(HT)), rowP = (u32)(M * (p8 ? 1 : 4));
                     auto store_row = [&](int k, u32 h, u32 pr) {
                         if constexpr (sizeof(HT) == 8) {
                             typedef int v2i __attribute__((ext_vector_type(2)));
@@ -863,21 +872,26 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                         } else {
                             __builtin_amdgcn_raw_buffer_store_b32((int)h, rH, voffH, (int)(rowH * (u32)k), 0);
                         }
-                        __builtin_amdgcn_raw_buffer_store_b32((int)pr, rP, voffP, (int)(rowP * (u32)k), 0);
+                        if (p8) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)pr, rP, voffP, (int)(rowP * (u32)k), 0);
+                        else __builtin_amdgcn_raw_buffer_store_b32((int)pr, rP, voffP, (int)(rowP * (u32)k), 0);
                         if (right_lane) p.right[r0 + k] = (int)h;   // the tile's right edge column, for the next tile of this band
                     };
                     u32 blkmax = 0;
                     if (nb == SY_U && !right_strip) {
                         // the common case: whole block in one asm statement
                         u32 z = (u32)(cz + ngap * (r0 - 1));
-                        const uint64_t bH = (uint64_t)(uintptr_t)(H + (int64_t)r0 * M), bP = (uint64_t)(uintptr_t)(P + (int64_t)r0 * M);
+                        const uint64_t bH = (uint64_t)(uintptr_t)(H + (int64_t)r0 * M), bP = (uint64_t)(uintptr_t)Prow;
                         const sw_i32x4 dH = {(int)(u32)bH, (int)(u32)(bH >> 32), 0x7FFFFF00, 0x00020000};
                         const sw_i32x4 dP = {(int)(u32)bP, (int)(u32)(bP >> 32), 0x7FFFFF00, 0x00020000};
-                        if constexpr (sizeof(HT) == 8) {
-                            if (p.store_nt) consumer_block16_h64<true>(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, voffH, dH, dP, rowP, rowH, seq_b + (r0 - 1));
-                            else consumer_block16_h64<false>(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, voffH, dH, dP, rowP, rowH, seq_b + (r0 - 1));
-                        } else if (p.store_nt) consumer_block16<true>(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, dH, dP, rowP, seq_b + (r0 - 1));
-                        else consumer_block16<false>(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, dH, dP, rowP, seq_b + (r0 - 1));
+                        const unsigned char* ch = seq_b + (r0 - 1);
+                        auto run = [&](auto NT, auto P8) {
+                            if constexpr (sizeof(HT) == 8)
+                                consumer_block16_h64<decltype(NT)::value, decltype(P8)::value>(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, voffH, dH, dP, rowP, rowH, ch);
+                            else
+                                consumer_block16<decltype(NT)::value, decltype(P8)::value>(gv, z, blkmax, a_lu, mm_v, xm_v, ngap_v, voffP, voffH, dH, dP, rowP, rowH, ch);
+                        };
+                        if (p.store_nt) { if (p8) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
+                        else { if (p8) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
                     } else if (nb == SY_U) {
                         const uint4 w = *reinterpret_cast<const uint4*>(seq_b + (r0 - 1));  // this block's 16 row characters
                         const u32 bw[4] = {(u32)__builtin_amdgcn_readfirstlane((int)w.x), (u32)__builtin_amdgcn_readfirstlane((int)w.y),

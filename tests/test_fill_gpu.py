@@ -169,6 +169,37 @@ def test_tuning_options_do_not_change_results(engine, oracle, engine_kind, opts,
             engine.set_option(k, v)
 
 
+@pytest.mark.parametrize("h64", [False, True], ids=["h32", "h64"])
+@pytest.mark.parametrize("cols,rows", [(1000, 700), (63, 16), (4200, 1300), (130, 1029)])
+def test_compact_p_int8(engine, oracle, swamd, engine_kind, cols, rows, h64):
+    """sw_fill_device_ex with one byte per predecessor code: same H, arg-max, codes, traceback and checksums."""
+    import torch
+    a, b = oracle.generate(cols, rows, 29)
+    if engine_kind != 0:
+        with pytest.raises(swamd.SwError):
+            engine.fill(a, b, p_dtype=torch.int8)
+        return
+    H, P, mp = oracle.fill(a, b)
+    for policy in (1, 2):
+        engine.set_option("store_policy", policy)
+        try:
+            out = engine.fill(a, b, h_dtype=torch.int64 if h64 else None, p_dtype=torch.int8)
+        finally:
+            engine.set_option("store_policy", 0)
+        assert out.P.dtype == torch.int8
+        assert np.array_equal(out.H.cpu().numpy().astype(np.int64), H.astype(np.int64))
+        assert np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
+        assert out.result()["max_pos"] == mp
+        assert np.array_equal(engine.row_checksums(out.P), oracle.row_checksums(P))   # int8 P checksums like its int32 widening
+    P8 = out.P.cpu().numpy().copy()
+    path = engine.traceback(out, mp)
+    P1 = P.copy()
+    opath = oracle.backtrack(P1, mp)
+    assert np.array_equal(path, opath) and np.array_equal(out.P.cpu().numpy().astype(np.int32), P1)
+    hpath = swamd.traceback_host(P8, mp)
+    assert np.array_equal(hpath, opath) and np.array_equal(P8.astype(np.int32), P1)
+
+
 def test_full_size_16384_streaming_checksums(engine, oracle, swamd):
     """BASELINE config 2 (16384 x 16384 int32): per-row checksums + arg-max vs the streaming oracle."""
     a, b = swamd.generate(16384, 16384, 1)
