@@ -23,10 +23,24 @@ step bench_strip_scan 200 python bench.py --steps 5 --warmup 1 --no-cpu --engine
 step bench_h64_32k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 32768 --rows 32768 --h64 --placement-trials 2
 step bench_h64_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64 --placement-trials 1
 step bench_i32_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --placement-trials 1
+step bench_p8 300 python bench.py --steps 10 --warmup 2 --no-cpu --p8
+step bench_p8_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --p8 --placement-trials 1
+step bench_bands 300 python bench.py --steps 3 --warmup 1 --mode bands
 step bench_batch_1k 300 python bench.py --steps 3 --warmup 1 --mode batch --cols 1024 --rows 1024 --pairs 100000
 step bench_batch_1k_stored 300 python bench.py --steps 3 --warmup 1 --mode batch --cols 1024 --rows 1024 --pairs 512 --store
 export TMPDIR=/tmp
-# same command under the profiler; one placement only, so that every sw_systolic launch in the trace is a launch of the
-# timed configuration (the stats average is then comparable with the JSON line this run prints)
-step rocprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 20 --warmup 3 --no-cpu --placement-trials 1
+# the default bench command under the profiler.  The trace also holds the placement-trial and warm-up launches, so
+# besides rocprofv3's own stats the average of the LAST 20 sw_systolic launches (= the timed steps) is derived from
+# the kernel trace; that is the number to compare with roofline.avg_launch_ms of the JSON line this run prints.
+rm -rf gpurun_out/prof
+step rocprof 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 20 --warmup 3 --no-cpu
+python3 - <<'PY' | tee gpurun_out/rocprof_timed_launches.txt
+import csv, glob
+for f in glob.glob("gpurun_out/prof/**/*kernel_trace.csv", recursive=True):
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if "sw_systolic" in r["Kernel_Name"]]
+    if len(d) >= 20:
+        t = d[-20:]
+        print(f"{f}: {len(d)} sw_systolic launches in the trace; the last 20 (the timed steps): avg {sum(t)/20/1e6:.4f} ms, min {min(t)/1e6:.4f}, max {max(t)/1e6:.4f}; "
+              f"all launches: avg {sum(d)/len(d)/1e6:.4f} ms")
+PY
 find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -8 "$f"; done

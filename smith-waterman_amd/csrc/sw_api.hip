@@ -34,8 +34,8 @@ struct sw_ctx {
     int64_t opt_pace_ps = 0;            // systolic: pacing of strip 0 (ps per row; 0 = off)
     int64_t opt_dbg_ptr = 0;
     int64_t opt_engine = 0;             // 0 = systolic producer/consumer pipeline, 1 = strip_scan (row scan)
-    int64_t opt_strips_per_group = 2;   // systolic: producer waves (strips) per workgroup
-    int64_t opt_consumers = 4;          // systolic: consumer waves per strip
+    int64_t opt_strips_per_group = 0;   // systolic: producer waves (strips) per workgroup; 0 = by problem shape
+    int64_t opt_consumers = 0;          // systolic: consumer waves per strip; 0 = by problem shape
     int64_t opt_waves_per_block = 4;
     int64_t opt_max_blocks = 0;         // 0 -> 2 * CUs
     int64_t last_grid = 0, last_strips = 0;
@@ -78,8 +78,8 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
         return SW_OK;
     }
     if (!strcmp(name, "max_blocks")) { c->opt_max_blocks = v < 0 ? 0 : v; return SW_OK; }
-    if (!strcmp(name, "strips_per_group")) { c->opt_strips_per_group = v ? v : 2; return SW_OK; }
-    if (!strcmp(name, "consumers")) { c->opt_consumers = v ? v : 4; return SW_OK; }
+    if (!strcmp(name, "strips_per_group")) { c->opt_strips_per_group = v; return SW_OK; }
+    if (!strcmp(name, "consumers")) { c->opt_consumers = v; return SW_OK; }
     if (!strcmp(name, "debug_flags")) { c->opt_debug = v; return SW_OK; }
     if (!strcmp(name, "pace_ps")) { c->opt_pace_ps = v; return SW_OK; }
     if (!strcmp(name, "store_policy")) { if (v < 0 || v > 2) return SW_EINVAL; c->opt_store_policy = v; return SW_OK; }
@@ -182,7 +182,12 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
     const unsigned char* ua = (const unsigned char*)j.d_a;
     const unsigned char* ub = (const unsigned char*)j.d_b;
     if (systolic) {
-        const int NS = (int)c->opt_strips_per_group, NC = (int)c->opt_consumers;
+        // Workgroup shape.  One strip + 8 consumers per workgroup spreads a single pair over every CU (measured at
+        // 4096^2..16384^2: equal to 4 % faster than 2 + 2x4); with more strips than CUs -- big matrices, batches --
+        // two strips per workgroup do twice the work per CU (batch of 1024^2 pairs: 415 vs 194 GCUPS).
+        int NS = (int)c->opt_strips_per_group, NC = (int)c->opt_consumers;
+        if (NS == 0) NS = ((double)S * (double)j.npairs <= 1.1 * c->num_cus) ? 1 : 2;
+        if (NC == 0) NC = (NS == 1) ? 8 : 4;
         // padded copies of b per problem: [front | b | tail]; front covers the fast producers' phi (< strips) + 63 lanes
         const int64_t bfront = ((S + 64 + 127) / 128) * 128;
         const int64_t per = ((rows + bfront + 512 + 15) / 16) * 16;
