@@ -212,6 +212,23 @@ def test_full_size_16384_streaming_checksums(engine, oracle, swamd):
     assert np.array_equal(out.H[-1].cpu().numpy(), st["bottom"])
     n = engine.traceback(out, want_path=False)
     assert 16384 < n < 3 * 16384
+    if engine.get_option("engine") == 0:
+        # the same workload with the compact predecessor matrix and with the other workgroup shape / store policy:
+        # identical checksums (an int8 P checksums like its int32 widening), arg-max and path length
+        import torch
+        for opts, p_dtype in (({}, torch.int8), ({"strips_per_group": 2, "consumers": 4, "store_policy": 1}, None)):
+            for k, v in opts.items():
+                engine.set_option(k, v)
+            try:
+                o2 = engine.fill(a, b, p_dtype=p_dtype)
+            finally:
+                for k in opts:
+                    engine.set_option(k, 0)
+            r2 = o2.result()
+            assert r2["max_pos"] == st["max_pos"] and r2["max_score"] == st["max_score"]
+            assert np.array_equal(engine.row_checksums(o2.H), st["csH"]) and np.array_equal(engine.row_checksums(o2.P), st["csP"])
+            assert engine.traceback(o2, want_path=False) == n
+            del o2
 
 
 @pytest.mark.skipif(not os.environ.get("SW_BIG"), reason="BASELINE config 3 at full size: set SW_BIG=1 (needs ~55 GB of HBM, ~40 s of host time)")
