@@ -1,4 +1,4 @@
-for i in 1 2 3 4 5 6; do python bench.py --no-cpu --steps 20 --warmup 3 2>&1 | python3 -c "
+for i in 1 2 3 4 5 6 7 8; do python bench.py --no-cpu --steps 20 --warmup 3 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -204,7 +204,7 @@ class Engine:
             d[: len(s)] = t.from_numpy(s.copy())
         return d, len(s)
 
-    def alloc(self, cols: int, rows: int, h_dtype=None, p_dtype=None, spacer_bytes: int = 0):
+    def alloc(self, cols: int, rows: int, h_dtype=None, p_dtype=None, spacer_bytes: int = 0, hold=None):
         """Output buffers: H int32|int64, P int32 (the reference layout) or int8 (compact P, same codes).
         spacer_bytes: a block of that size is allocated between H and P and released again, so that the two
         matrices land in different regions of the device memory (used by alloc_tuned)."""
@@ -234,10 +234,14 @@ class Engine:
         else:
             P = t.empty((rows + 1, cols + 1), dtype=t.int32, device=dev)
         res = t.zeros(3, dtype=t.int64, device=dev)
+        out = Fill(H, P, res, cols, rows)
         if spacer is not None:
-            del spacer
-            t.cuda.empty_cache()
-        return Fill(H, P, res, cols, rows)
+            if hold is not None:
+                hold.append(spacer)     # the caller keeps it (so that later allocations explore other regions) and frees it
+            else:
+                del spacer
+                t.cuda.empty_cache()
+        return out
 
     def alloc_tuned(self, d_a, d_b, cols: int, rows: int, h_dtype=None, trials: int = 4, fills: int = 3, p_dtype=None):
         """alloc() with placement tuning: the fill's speed depends on where the driver put H and P in
@@ -252,7 +256,7 @@ class Engine:
                 # candidates differ in how far apart H and P are allocated (measured: the fast mode is about six
                 # times more frequent among such pairs than among back-to-back allocations, scripts/ab_scan.py, ab_spacer.py)
                 sp = ((i % 6) * 5 + 3) << 30 if (i > 0 and n_bytes < (4 << 30)) else 0
-                cand = self.alloc(cols, rows, h_dtype, p_dtype, spacer_bytes=sp)
+                cand = self.alloc(cols, rows, h_dtype, p_dtype, spacer_bytes=sp, hold=held)
             except RuntimeError:      # out of HBM: stay with what we have
                 break
             self.fill_into(cand, d_a, d_b)
