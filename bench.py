@@ -219,7 +219,7 @@ def main():
         traffic = None   # HBM bytes per launch from the PMC passes (scripts/gpu_pmc.sh), when they exist for this workload
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if pm["workload"] == f"{cols}x{rows} {'int64' if args.h64 else 'int32'} engine={'systolic' if args.engine == 0 else 'strip_scan'}":
+            if not args.p8 and pm["workload"] == f"{cols}x{rows} {'int64' if args.h64 else 'int32'} engine={'systolic' if args.engine == 0 else 'strip_scan'}":
                 traffic = pm["traffic_bytes_per_launch"]
         except Exception:
             pass

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc
 for c in WRITE_SIZE FETCH_SIZE; do
-  timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/bench_$c -- python bench.py --steps 3 --warmup 1 --no-cpu > gpurun_out/pmc/bench_$c.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/bench_$c -- python bench.py --steps 10 --warmup 1 --no-cpu --placement-trials 1 > gpurun_out/pmc/bench_$c.log 2>&1
   echo "bench $c rc=$?"
   timeout -k 10 100 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc/calib_$c -- ./tools/ubench_store > gpurun_out/pmc/calib_$c.log 2>&1
   echo "calib $c rc=$?"
