@@ -31,7 +31,12 @@
 // Roles in one workgroup (NS strips): NS producer waves, NS*NC consumer waves (derive H and P
 // from the ring, row-major coalesced HBM stores, arg-max), an importer and an exporter wave (move the
 // edge column between workgroups through HBM/L2 as {tag,value} granules).  Hand-offs inside the workgroup are
-// LDS counters written in order behind the data they cover.
+// LDS counters written in order behind the data they cover.  Shapes: NS=1 with 8 consumers while the
+// strips of the job fit the CUs (the producer then has a SIMD to itself: 20 ns per step), NS=2 with
+// 2x4 consumers otherwise (twice the work per CU; VALU-bound at 27 ns per step).
+// Both hot loops are single asm statements: producer_fast (the whole strip loop) and
+// consumer_block16 (16 matrix rows: H, P, both stores; int32/int64 H, int32/int8 P, write-back or
+// streaming stores).  DESIGN.md sections 5 and 6 have the measurements behind every choice.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
