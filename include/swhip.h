@@ -151,8 +151,8 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
 /* ---- tuning knobs (0 = built-in default) --------------------------------------------------
  * None of them changes a result bit; they only move time.
  *   "engine"            0 systolic (default), 1 strip_scan
- *   "strips_per_group"  systolic: strips (producer waves) per workgroup, 1 or 2 (0: 1 while the strips of the job
- *                       fit the CUs, else 2)
+ *   "strips_per_group"  systolic: strips (producer waves) per workgroup, 1 or 2 (0: 1 for a single pair with up to
+ *                       4.5 strips per CU or a batch that fits the CUs at once, else 2)
  *   "consumers"         systolic: consumer waves per strip: 2, 3, 4; also 6, 8 with one strip per group (0: 8 / 4)
  *   "store_policy"      systolic H/P stores: 0 by problem size, 1 write-back, 2 streaming (nt)
  *   "xcd_order"         systolic: 1 = neighbouring strip groups run on the same XCD

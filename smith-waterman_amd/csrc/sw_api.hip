@@ -182,11 +182,12 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
     const unsigned char* ua = (const unsigned char*)j.d_a;
     const unsigned char* ub = (const unsigned char*)j.d_b;
     if (systolic) {
-        // Workgroup shape.  One strip + 8 consumers per workgroup spreads a single pair over every CU (measured at
-        // 4096^2..16384^2: equal to 4 % faster than 2 + 2x4); with more strips than CUs -- big matrices, batches --
-        // two strips per workgroup do twice the work per CU (batch of 1024^2 pairs: 415 vs 194 GCUPS).
+        // Workgroup shape.  One strip + 8 consumers per workgroup gives every producer a SIMD of its own (measured on
+        // single pairs from 4096^2 to 32768^2: equal to 5 % faster than 2 + 2x4, equal at 65536^2); batches that
+        // do not fit the CUs at once run two strips per workgroup, twice the work per CU (1024^2 pairs: 415 vs 194 GCUPS
+        // for 20000 pairs, 203 vs 143 for 64).
         int NS = (int)c->opt_strips_per_group, NC = (int)c->opt_consumers;
-        if (NS == 0) NS = ((double)S * (double)j.npairs <= 1.1 * c->num_cus) ? 1 : 2;
+        if (NS == 0) NS = (j.npairs == 1 ? (double)S <= 4.5 * c->num_cus : (double)S * (double)j.npairs <= (double)c->num_cus) ? 1 : 2;
         if (NC == 0) NC = (NS == 1) ? 8 : 4;
         // padded copies of b per problem: [front | b | tail]; front covers the fast producers' phi (< strips) + 63 lanes
         const int64_t bfront = ((S + 64 + 127) / 128) * 128;
