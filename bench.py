@@ -130,6 +130,7 @@ def main():
                     help="pair mode: candidate H/P allocations tried before the timed region (1 = take the first)")
     ap.add_argument("--store-policy", type=int, default=0, help="systolic H/P stores: 0 auto, 1 write-back, 2 streaming")
     ap.add_argument("--xcd-order", type=int, default=0, help="systolic: neighbouring strip groups on one XCD")
+    ap.add_argument("--importers", type=int, default=0, help="systolic, one strip per workgroup: importer waves (1 or 2)")
     ap.add_argument("--pace", type=int, default=-1, help="systolic: strip-0 pacing in ps per row (0 = off, -1 = library default)")
     ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--wpb", type=int, default=0)
@@ -151,6 +152,8 @@ def main():
     eng.set_option("engine", args.engine)
     if args.pace >= 0:
         eng.set_option("pace_ps", args.pace)
+    if args.importers:
+        eng.set_option("importers", args.importers)
     if args.store_policy:
         eng.set_option("store_policy", args.store_policy)
     if args.xcd_order:

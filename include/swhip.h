@@ -155,6 +155,8 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       4.5 strips per CU or a batch that fits the CUs at once, else 2)
  *   "consumers"         systolic: consumer waves per strip: 2, 3, 4; also 6, 8 with one strip per group (0: 8 / 4)
  *   "store_policy"      systolic H/P stores: 0 by problem size, 1 write-back, 2 streaming (nt)
+ *   "importers"         systolic, one strip per workgroup: waves polling the left neighbour's edge column (default 2;
+ *                       at most what 12 waves per workgroup leave)
  *   "xcd_order"         systolic: 1 = neighbouring strip groups run on the same XCD
  *   "pace_ps"           systolic: strip 0 releases one row per this many picoseconds (0 = unpaced)
  *   "waves_per_block", "max_blocks", "debug_flags", "debug_buf"   development aids */

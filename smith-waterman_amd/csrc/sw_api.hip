@@ -31,6 +31,7 @@ struct sw_ctx {
     int64_t opt_debug = 0;
     int64_t opt_store_policy = 0;       // systolic H/P stores: 0 auto (by size), 1 write-back, 2 streaming (nt)
     int64_t opt_xcd_order = 0;          // systolic: 1 = neighbouring strip groups on one XCD
+    int64_t opt_importers = 2;          // systolic, one strip per workgroup: importer waves (as far as 12 waves allow)
     int64_t opt_pace_ps = 0;            // systolic: pacing of strip 0 (ps per row; 0 = off)
     int64_t opt_dbg_ptr = 0;
     int64_t opt_engine = 0;             // 0 = systolic producer/consumer pipeline, 1 = strip_scan (row scan)
@@ -84,6 +85,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "pace_ps")) { c->opt_pace_ps = v; return SW_OK; }
     if (!strcmp(name, "store_policy")) { if (v < 0 || v > 2) return SW_EINVAL; c->opt_store_policy = v; return SW_OK; }
     if (!strcmp(name, "xcd_order")) { c->opt_xcd_order = v ? 1 : 0; return SW_OK; }
+    if (!strcmp(name, "importers")) { if (v < 0 || v > 8) return SW_EINVAL; c->opt_importers = v ? v : 2; return SW_OK; }
     if (!strcmp(name, "debug_buf")) { c->opt_dbg_ptr = v; return SW_OK; }
     if (!strcmp(name, "engine")) {
         if (v != 0 && v != 1) { set_err("engine must be 0 (systolic) or 1 (strip_scan)"); return SW_EINVAL; }
@@ -103,6 +105,7 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "consumers")) return c->opt_consumers;
     if (!strcmp(name, "store_policy")) return c->opt_store_policy;
     if (!strcmp(name, "xcd_order")) return c->opt_xcd_order;
+    if (!strcmp(name, "importers")) return c->opt_importers;
     if (!strcmp(name, "pace_ps")) return c->opt_pace_ps;
     if (!strcmp(name, "num_cus")) return c->num_cus;
     if (!strcmp(name, "last_grid")) return c->last_grid;
@@ -212,7 +215,9 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : (int64_t)c->num_cus;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ngroups, maxb));
         c->last_grid = grid; c->last_strips = S;
-        const int threads = 64 * (NS * (1 + NC) + 2);
+        const int base_waves = NS * (1 + NC) + 2;
+        const int extra_imp = (NS == 1) ? (int)std::max<int64_t>(0, std::min<int64_t>(c->opt_importers - 1, 12 - base_waves)) : 0;
+        const int threads = 64 * (base_waves + extra_imp);
         const unsigned char* cbp = c->d_cb;
         bool launched = false;
 #define SW_LAUNCH(ns, nc)                                                                                                        \

@@ -611,7 +611,7 @@ __device__ __forceinline__ void consumer_block16_h64(const u32 (&g)[SY_U + 1], u
 }
 
 template <typename HT, int NS, int NC>
-__global__ void __launch_bounds__(64 * (NS * (1 + NC) + 2))
+__global__ void __launch_bounds__(NS == 1 ? 64 * 12 : 64 * (NS * (1 + NC) + 2))   // NS == 1: up to 12 waves, the spare ones are extra importers
 sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsigned char* bpad, FillParams p) {
     __shared__ SysLds<NS> lds;
     const int lane = threadIdx.x & 63;
@@ -670,7 +670,9 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
         constexpr bool helpers_mid = (NS == 2 && NWAVES > 6);
         constexpr bool helpers_s0 = (NS == 1 && NWAVES >= 9);
         const int h_imp = (helpers_mid || helpers_s0) ? 4 : NWAVES - 2, h_exp = helpers_mid ? 5 : helpers_s0 ? 8 : NWAVES - 1;
-        const bool is_helper = (wave == h_imp || wave == h_exp);
+        // optional extra importers (launched as extra waves, NS == 1 only): several waves polling the same edge
+        // column cut the time a freshly exported row waits for the next polling load
+        const bool is_helper = (wave == h_imp || wave == h_exp || wave >= NWAVES);
         const int cw = wave - NS - (wave > h_imp ? 1 : 0) - (wave > h_exp ? 1 : 0);  // consumer ordinal 0..NS*NC-1
         if (wave < NS) {
             // ================================ producer ================================
@@ -977,7 +979,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 ok = (gr >> 32) == (tag_base | (u64)r);
                 return (u32)gr;
             };
-            const bool importer = (wave == h_imp), exporter = !importer;  // one wave each
+            const bool importer = (wave == h_imp || wave >= NWAVES), exporter = (wave == h_exp);
             while ((importer && imp <= rows) || (exporter && do_export && exp <= rows)) {
                 bool progressed = false;
                 if (importer && imp <= rows) {
@@ -1042,7 +1044,8 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                         asm volatile("" ::: "memory");  // LDS executes a wave's ops in order: data before counter
                         if (p.dbg && lane == 0 && imp <= rows / 2 && base > rows / 2) p.dbg[2 * p.nstrips + 8 + 2 * grp] = __builtin_amdgcn_s_memrealtime();
                         imp = base;
-                        lds_store(&lds.halo_ready, imp + phi0);  // local steps < imp+phi0 are in halo[]
+                        // local steps < imp+phi0 are in halo[] (a maximum: with two importers the slower one must not take it back)
+                        __hip_atomic_fetch_max(&lds.halo_ready, imp + phi0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         progressed = true;
                     }
                 }
