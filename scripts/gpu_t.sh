@@ -1,7 +1,5 @@
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 || exit 1
-for i in 1 2 3; do for v in base prev; do
-  if [ $v = base ]; then unset SWHIP_LIBRARY; else export SWHIP_LIBRARY=$PWD/build/libswhip_$v.so; fi
-  echo -n "$v: "; python bench.py --no-cpu --steps 20 --warmup 3 2>&1 | python3 -c "
+for i in 1 2; do for cfg in "8 2" "7 3" "7 2"; do set -- $cfg
+  echo -n "nc=$1 importers=$2: "; python bench.py --no-cpu --steps 20 --warmup 3 --ns 1 --nc $1 --importers $2 2>&1 | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
