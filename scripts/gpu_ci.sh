@@ -21,10 +21,10 @@ step pytest_gpu 600 python -m pytest tests -m gpu -x -q
 step bench 400 python bench.py --steps 10 --warmup 2
 step bench_strip_scan 200 python bench.py --steps 5 --warmup 1 --no-cpu --engine 1
 step bench_h64_32k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 32768 --rows 32768 --h64 --placement-trials 2
-step bench_h64_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64 --placement-trials 1
-step bench_i32_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --placement-trials 1
+step bench_h64_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64 --placement-trials 3
+step bench_i32_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --placement-trials 3
 step bench_p8 300 python bench.py --steps 10 --warmup 2 --no-cpu --p8
-step bench_p8_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --p8 --placement-trials 1
+step bench_p8_64k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --p8 --placement-trials 3
 step bench_bands 300 python bench.py --steps 3 --warmup 1 --mode bands
 step bench_batch_1k 300 python bench.py --steps 3 --warmup 1 --mode batch --cols 1024 --rows 1024 --pairs 100000
 step bench_batch_1k_stored 300 python bench.py --steps 3 --warmup 1 --mode batch --cols 1024 --rows 1024 --pairs 512 --store
