@@ -45,7 +45,11 @@ typedef struct { int32_t match, mismatch, gap; } sw_scores;
  * path_len: cells negated by the traceback (0 until a traceback ran). */
 typedef struct { int64_t max_pos; int64_t max_score; int64_t path_len; } sw_result;
 
-typedef struct sw_ctx sw_ctx; /* one per GPU; one host thread drives a ctx at a time */
+/* One per GPU; one host thread drives a ctx at a time.  Fills of one DEVICE are serialised by the library (a fill's
+ * workgroups wait for each other, so two fills must not share the CUs): a fill enqueued on another stream than the
+ * previous fill of that device first waits, on the device, for that stream.  Contexts of different devices are
+ * independent. */
+typedef struct sw_ctx sw_ctx;
 
 const char* sw_last_error(void);
 const char* sw_version(void);
@@ -87,9 +91,13 @@ int sw_fill_device(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, 
                    const sw_scores* scores, void* d_H, int h_elem_bytes, int32_t* d_P,
                    const int32_t* d_top, sw_result* d_result, void* stream);
 
-/* Same with a compact predecessor matrix: p_elem_bytes 4 -> d_P is int32_t* (identical to
- * sw_fill_device), 1 -> d_P is int8_t* holding the same codes (0..3; -1..-3 after a traceback), a quarter of
- * the P traffic and footprint.  Systolic engine only. */
+/* Same with a compact predecessor matrix and/or without one of the matrices (the rolling-buffer
+ * variants of the reference, rotated-cuda/sw-rotated-omp.cc:214-224, likewise keep only what the caller asks for):
+ *   p_elem_bytes 4 -> d_P is int32_t* (identical to sw_fill_device), 1 -> d_P is int8_t* holding the same codes
+ *                (0..3; -1..-3 after a traceback): a quarter of the P traffic and footprint;
+ *   d_H == NULL  -> H is not written ("P-only": 1 or 4 B/cell, enough for the traceback);
+ *   d_P == NULL  -> P is not written; both NULL = score-only.
+ * max_pos / max_score are exact in every mode.  Systolic engine only. */
 int sw_fill_device_ex(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, int64_t rows,
                       const sw_scores* scores, void* d_H, int h_elem_bytes, void* d_P, int p_elem_bytes,
                       const int32_t* d_top, sw_result* d_result, void* stream);
@@ -106,13 +114,43 @@ int sw_fill_tile_device(sw_ctx* ctx, const char* d_a, int64_t cols, const char* 
                         const int32_t* d_top, const int32_t* d_left, int32_t* d_right, sw_result* d_result,
                         void* stream);
 
+/* One ROW BAND of a bigger (total_rows+1) x (cols+1) matrix as ONE persistent launch: the multi-GPU decomposition of
+ * SURVEY.md 8e (the reference has no multi-GPU code; the order preserved is omp_smithW.c:203-216).  The band's halo
+ * row arrives and its last row leaves as 8-byte granules  (uint64)tag << 32 | (uint32)H  , one per column, WHILE the
+ * kernel runs: a strip starts as soon as its 64 granules of the row above carry `top_tag`, so the launch can be
+ * enqueued before the band above has produced anything, and whoever moves the halo (RCCL recv, a copy, a peer store)
+ * may deliver it in any order and chunking -- the data is its own flag.
+ *   d_H, d_P      : band-local (rows+1) x (cols+1) storage; row 0 is the halo row (H written, P left alone).  Either
+ *                   may be NULL (not written), p_elem_bytes 4 or 1 as in sw_fill_device_ex
+ *   d_top_gran    : cols+1 granules of the row above, or NULL for the first band (zeros)
+ *   d_bot_gran    : receives cols+1 granules of the band's last row (tag = bot_tag), or NULL
+ *   d_bot_done    : optional, one uint32 per 63-column strip (ceil(cols/63)), may be host-pinned memory: set to bot_tag,
+ *                   system scope, after the strip's granules were released -- lets a host thread forward finished chunks
+ *   tags          : non-zero, and different from what the buffers held before (e.g. a per-fill counter)
+ *   reserve_cus   : CUs the launch leaves free for other kernels (halo transfers); 0 = use all
+ *   concurrent    : non-zero = do not order this launch behind fills on other streams of the device (the caller keeps
+ *                   the sum of the grids within the CUs, option "max_blocks")
+ *   d_result      : band-local arg-max (max_pos relative to the band's row 0, stride cols+1)
+ * total_rows bounds the scores a halo can carry (range check).  Patience of the halo poll: option "band_wait_ms". */
+int sw_fill_band_device(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, int64_t rows, int64_t total_rows,
+                        const sw_scores* scores, void* d_H, int h_elem_bytes, void* d_P, int p_elem_bytes,
+                        const uint64_t* d_top_gran, uint32_t top_tag, uint64_t* d_bot_gran, uint32_t bot_tag,
+                        uint32_t* d_bot_done, int reserve_cus, int concurrent, sw_result* d_result, void* stream);
+
 /* Batch of npairs independent cols x rows problems (BASELINE config 5): pair k reads a at
- * d_a + k*a_stride and b at d_b + k*b_stride (b_stride a multiple of 16), writes d_results[k] and, when
- * d_H/d_P are given (both or neither), its matrices at offset k*(rows+1)*(cols+1).  Without matrices the
- * fill is score-only: max_score is exact, max_pos is the first row of the 16-row block holding it. */
+ * d_a + k*a_stride and b at d_b + k*b_stride (b_stride a multiple of 16), writes d_results[k] (exact arg-max in
+ * every mode) and, where given, its matrices at element offset k*(rows+1)*(cols+1).  d_H and/or d_P may be NULL. */
 int sw_batch_device(sw_ctx* ctx, const char* d_a, int64_t a_stride, int64_t cols, const char* d_b, int64_t b_stride,
                     int64_t rows, int64_t npairs, const sw_scores* scores, int32_t* d_H, int32_t* d_P,
                     sw_result* d_results, void* stream);
+/* the same with a compact predecessor matrix: p_elem_bytes 1 -> d_P is int8_t* (100 000 x 1025^2 codes = 105 GB) */
+int sw_batch_device_ex(sw_ctx* ctx, const char* d_a, int64_t a_stride, int64_t cols, const char* d_b, int64_t b_stride,
+                       int64_t rows, int64_t npairs, const sw_scores* scores, int32_t* d_H, void* d_P, int p_elem_bytes,
+                       sw_result* d_results, void* stream);
+/* backtrack() (serial_smithW.c:262-277) of every pair of a batch: walks pair k's P from d_results[k].max_pos, negates
+ * the path, sets d_results[k].path_len; d_paths (optional, npairs x path_cap) receives the visited pair-local indices. */
+int sw_batch_traceback_device(sw_ctx* ctx, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t npairs,
+                              int64_t* d_paths, int64_t path_cap, sw_result* d_results, void* stream);
 
 /* Host-buffer convenience wrapper around sw_fill_device (alloc, H2D, fill, D2H, sync).
  * H, P: caller-owned int32 (rows+1)*(cols+1); either may be NULL to skip its copy-out. */
@@ -159,7 +197,10 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       at most what 12 waves per workgroup leave)
  *   "xcd_order"         systolic: 1 = neighbouring strip groups run on the same XCD
  *   "pace_ps"           systolic: strip 0 releases one row per this many picoseconds (0 = unpaced)
- *   "waves_per_block", "max_blocks", "debug_flags", "debug_buf"   development aids */
+ *   "band_wait_ms"      sw_fill_band_device: how long a strip waits for its halo granules before the launch aborts
+ *                       with SW_ETIMEOUT (default 20000)
+ *   "max_blocks"        cap of the resident grid (0 = all CUs); concurrent band launches partition the CUs with it
+ *   "waves_per_block", "debug_flags", "debug_buf"   development aids */
 int sw_set_option(sw_ctx* ctx, const char* name, int64_t value);
 int64_t sw_get_option(sw_ctx* ctx, const char* name);
 

@@ -54,6 +54,10 @@ ABI = {
     "sw_fill_device": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _i32, _vp, _vp, _vp, _vp]),
     "sw_fill_tile_device": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sw_batch_device": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, ctypes.POINTER(_Scores), _vp, _vp, _vp, _vp]),
+    "sw_batch_device_ex": (_i32, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, ctypes.POINTER(_Scores), _vp, _vp, _i32, _vp, _vp]),
+    "sw_batch_traceback_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
+    "sw_fill_band_device": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, ctypes.POINTER(_Scores), _vp, _i32, _vp, _i32, _vp, _u32, _vp, _u32, _vp,
+                                   _i32, _i32, _vp, _vp]),
     "sw_fill_host": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result)]),
     "sw_traceback_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "sw_traceback_host": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
@@ -146,8 +150,8 @@ def _as_seq(x) -> np.ndarray:
 
 @dataclass
 class Fill:
-    """Device-resident result of one DP fill. H: (rows+1, cols+1) int32|int64, P: int32, both torch
-    CUDA tensors; res: int64[3] tensor (max_pos, max_score, path_len)."""
+    """Device-resident result of one DP fill. H: (rows+1, cols+1) int32|int64, P: int32|int8, both torch
+    CUDA tensors (either may be None: not written); res: int64[3] tensor (max_pos, max_score, path_len)."""
     H: "torch.Tensor"
     P: "torch.Tensor"
     res: "torch.Tensor"
@@ -204,7 +208,8 @@ class Engine:
             d[: len(s)] = t.from_numpy(s.copy())
         return d, len(s)
 
-    def alloc(self, cols: int, rows: int, h_dtype=None, p_dtype=None, spacer_bytes: int = 0, hold=None):
+    def alloc(self, cols: int, rows: int, h_dtype=None, p_dtype=None, spacer_bytes: int = 0, hold=None, want_h: bool = True,
+              want_p: bool = True):
         """Output buffers: H int32|int64, P int32 (the reference layout) or int8 (compact P, same codes).
         spacer_bytes: a block of that size is allocated between H and P and released again, so that the two
         matrices land in different regions of the device memory (used by alloc_tuned)."""
@@ -213,6 +218,10 @@ class Engine:
         p_dtype = p_dtype or t.int32
         assert p_dtype in (t.int32, t.int8)
         dev = f"cuda:{self.device}"
+        if not (want_h and want_p):   # matrix-less fills (P-only, H-only, score-only): sw_fill_device_ex with NULL pointers
+            H = t.empty((rows + 1, cols + 1), dtype=h_dtype, device=dev) if want_h else None
+            P = t.empty((rows + 1, cols + 1), dtype=p_dtype, device=dev) if want_p else None
+            return Fill(H, P, t.zeros(3, dtype=t.int64, device=dev), cols, rows)
         H = t.empty((rows + 1, cols + 1), dtype=h_dtype, device=dev)
         n = (rows + 1) * (cols + 1)
         spacer = None
@@ -282,16 +291,17 @@ class Engine:
         """Asynchronous fill on torch's current stream into pre-allocated buffers."""
         t = self.torch
         sc = _Scores(*scores)
-        hb = 8 if out.H.dtype == t.int64 else 4
+        hb = 8 if (out.H is not None and out.H.dtype == t.int64) else 4
         _check(lib().sw_fill_device_ex(self._h, d_a.data_ptr(), out.cols, d_b.data_ptr(), out.rows, ctypes.byref(sc),
-                                       out.H.data_ptr(), hb, out.P.data_ptr(), out.P.element_size(),
+                                       out.H.data_ptr() if out.H is not None else None, hb,
+                                       out.P.data_ptr() if out.P is not None else None, out.P.element_size() if out.P is not None else 4,
                                        top.data_ptr() if top is not None else None, out.res.data_ptr(), self._stream()))
         return out
 
-    def fill(self, a, b, scores=DEFAULT_SCORES, h_dtype=None, top=None, p_dtype=None) -> Fill:
+    def fill(self, a, b, scores=DEFAULT_SCORES, h_dtype=None, top=None, p_dtype=None, want_h: bool = True, want_p: bool = True) -> Fill:
         d_a, cols = self.to_device(a)
         d_b, rows = self.to_device(b)
-        out = self.alloc(cols, rows, h_dtype, p_dtype)
+        out = self.alloc(cols, rows, h_dtype, p_dtype, want_h=want_h, want_p=want_p)
         if top is not None:
             top = self.torch.as_tensor(np.ascontiguousarray(top, np.int32)).to(f"cuda:{self.device}")
         self.fill_into(out, d_a, d_b, scores, top)
@@ -316,9 +326,25 @@ class Engine:
             top.data_ptr() if top is not None else None, left.data_ptr() if left is not None else None,
             right.data_ptr() if right is not None else None, res.data_ptr(), self._stream()))
 
-    def batch(self, a_all, b_all, scores=DEFAULT_SCORES, store: bool = False):
+    def fill_band(self, d_a, cols, d_b, rows, total_rows, H, P, res, top_gran=None, top_tag=0, bot_gran=None, bot_tag=0, bot_done=None,
+                  reserve_cus=0, concurrent=False, scores=DEFAULT_SCORES):
+        """Asynchronous band-resident launch (sw_fill_band_device): H/P (rows+1, cols+1) band-local tensors or None;
+        top_gran / bot_gran: int64 tensors with cols+1 granules (tag << 32 | H); bot_done: int32 tensor, one per strip
+        (device, or pinned host memory)."""
+        t = self.torch
+        sc = _Scores(*scores)
+        hb = 8 if (H is not None and H.dtype == t.int64) else 4
+        ptr = lambda x: x.data_ptr() if x is not None else None
+        _check(lib().sw_fill_band_device(self._h, d_a.data_ptr(), cols, d_b.data_ptr(), rows, total_rows, ctypes.byref(sc), ptr(H), hb,
+                                         ptr(P), P.element_size() if P is not None else 4, ptr(top_gran), top_tag, ptr(bot_gran), bot_tag,
+                                         ptr(bot_done), reserve_cus, 1 if concurrent else 0, res.data_ptr(), self._stream()))
+
+    def batch(self, a_all, b_all, scores=DEFAULT_SCORES, store: bool = False, p_dtype=None, store_h=None, traceback: bool = False,
+              want_paths: bool = False):
         """npairs independent problems (BASELINE config 5).  a_all: (npairs, cols) uint8, b_all: (npairs, rows).
-        Returns (results[npairs,3] int64 tensor, H, P) with H/P None unless store."""
+        store: write P (int32, or int8 with p_dtype=torch.int8) and -- unless store_h is False -- H of every pair.
+        traceback: also run backtrack() per pair (needs P); results[:, 2] then holds the path lengths.
+        Returns (results[npairs,3] int64 tensor, H, P) -- plus the paths tensor (npairs, cols+rows+2) when want_paths."""
         t = self.torch
         a_all = np.ascontiguousarray(a_all, np.uint8)
         b_all = np.ascontiguousarray(b_all, np.uint8)
@@ -333,14 +359,25 @@ class Engine:
         res = t.zeros((npairs, 3), dtype=t.int64, device=dev)
         H = P = None
         if store:
-            H = t.empty((npairs, rows + 1, cols + 1), dtype=t.int32, device=dev)
-            P = t.empty((npairs, rows + 1, cols + 1), dtype=t.int32, device=dev)
+            if store_h is None or store_h:
+                H = t.empty((npairs, rows + 1, cols + 1), dtype=t.int32, device=dev)
+            P = t.empty((npairs, rows + 1, cols + 1), dtype=p_dtype or t.int32, device=dev)
         sc = _Scores(*scores)
-        _check(lib().sw_batch_device(self._h, d_a.data_ptr(), cols, cols, d_b.data_ptr(), bstr, rows, npairs, ctypes.byref(sc),
-                                     H.data_ptr() if store else None, P.data_ptr() if store else None, res.data_ptr(),
-                                     self._stream()))
+        _check(lib().sw_batch_device_ex(self._h, d_a.data_ptr(), cols, cols, d_b.data_ptr(), bstr, rows, npairs, ctypes.byref(sc),
+                                        H.data_ptr() if H is not None else None, P.data_ptr() if P is not None else None,
+                                        P.element_size() if P is not None else 4, res.data_ptr(), self._stream()))
+        paths = None
+        if traceback:
+            assert P is not None, "the traceback walks P"
+            cap = cols + rows + 2
+            if want_paths:
+                paths = t.zeros((npairs, cap), dtype=t.int64, device=dev)
+            _check(lib().sw_batch_traceback_device(self._h, P.data_ptr(), P.element_size(), cols, rows, npairs,
+                                                   paths.data_ptr() if paths is not None else None, cap, res.data_ptr(), self._stream()))
         self.synchronize()
-        return res, H, P
+        if bool((res[:, 2] < 0).any().item()):
+            raise SwError(-62, "in-kernel hand-off wait timed out")
+        return (res, H, P, paths) if want_paths else (res, H, P)
 
     def traceback(self, out: Fill, max_pos: int | None = None, want_path: bool = True):
         """backtrack() on the device P (negates the path in place). Returns the path indices."""

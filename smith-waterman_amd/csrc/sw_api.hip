@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include "sw_kernels.h"
 
@@ -17,6 +18,20 @@ using swh::set_err;
             return SW_EDEVICE;                                                        \
         }                                                                             \
     } while (0)
+
+// Fills of one device are serialised.  The systolic kernel's workgroups spin on hand-offs from other workgroups, so
+// every workgroup of a launch must be resident; two fills in flight on one device (two contexts, or one context on
+// two streams) could each hold part of the CUs and wait for the rest forever.  Launches therefore happen under a
+// per-device lock, and a fill enqueued on a different stream than the previous one first waits (on the device, not
+// the host) for everything enqueued on that previous stream.
+struct DevState {
+    std::mutex mu;
+    bool any = false;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev = nullptr;
+    int concurrent_ok = 0;   // set while band launches that partition the CUs explicitly are being enqueued
+};
+static DevState g_dev[64];
 
 struct sw_ctx {
     int device = 0;
@@ -34,6 +49,7 @@ struct sw_ctx {
     int64_t opt_importers = 2;          // systolic, one strip per workgroup: importer waves (as far as 12 waves allow)
     int64_t opt_pace_ps = 0;            // systolic: pacing of strip 0 (ps per row; 0 = off)
     int64_t opt_dbg_ptr = 0;
+    int64_t opt_band_wait_ms = 20000;   // band-resident launch: patience of the top-halo poll
     int64_t opt_engine = 0;             // 0 = systolic producer/consumer pipeline, 1 = strip_scan (row scan)
     int64_t opt_strips_per_group = 0;   // systolic: producer waves (strips) per workgroup; 0 = by problem shape
     int64_t opt_consumers = 0;          // systolic: consumer waves per strip; 0 = by problem shape
@@ -87,6 +103,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "xcd_order")) { c->opt_xcd_order = v ? 1 : 0; return SW_OK; }
     if (!strcmp(name, "importers")) { if (v < 0 || v > 8) return SW_EINVAL; c->opt_importers = v ? v : 2; return SW_OK; }
     if (!strcmp(name, "debug_buf")) { c->opt_dbg_ptr = v; return SW_OK; }
+    if (!strcmp(name, "band_wait_ms")) { c->opt_band_wait_ms = v > 0 ? v : 20000; return SW_OK; }
     if (!strcmp(name, "engine")) {
         if (v != 0 && v != 1) { set_err("engine must be 0 (systolic) or 1 (strip_scan)"); return SW_EINVAL; }
         c->opt_engine = v;
@@ -107,23 +124,31 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "xcd_order")) return c->opt_xcd_order;
     if (!strcmp(name, "importers")) return c->opt_importers;
     if (!strcmp(name, "pace_ps")) return c->opt_pace_ps;
+    if (!strcmp(name, "band_wait_ms")) return c->opt_band_wait_ms;
     if (!strcmp(name, "num_cus")) return c->num_cus;
     if (!strcmp(name, "last_grid")) return c->last_grid;
     if (!strcmp(name, "last_strips")) return c->last_strips;
     return -1;
 }
 
-static int check_dims(int64_t cols, int64_t rows, const sw_scores* sc) {
-    if (cols < 0 || rows < 0 || cols > swk::SW_MAX_DIM || rows > swk::SW_MAX_DIM) {
+// gr, gc: extent (rows, cols) of the WHOLE matrix the values may come from (== rows, cols unless this is a tile or a
+// band whose halo carries scores accumulated outside it)
+static int check_dims(int64_t cols, int64_t rows, const sw_scores* sc, int64_t gc = -1, int64_t gr = -1) {
+    if (gc < cols) gc = cols;
+    if (gr < rows) gr = rows;
+    if (cols < 0 || rows < 0 || cols > swk::SW_MAX_DIM || rows > swk::SW_MAX_DIM || gc > swk::SW_MAX_DIM || gr > swk::SW_MAX_DIM) {
         set_err("dimensions out of range: cols=%lld rows=%lld (max %lld)", (long long)cols, (long long)rows,
                 (long long)swk::SW_MAX_DIM);
         return SW_EINVAL;
     }
     if (sc->gap > 0) { set_err("gap score must be <= 0 (got %d)", sc->gap); return SW_EINVAL; }
     if (sc->match < 0) { set_err("match score must be >= 0 (got %d)", sc->match); return SW_EINVAL; }
-    const int64_t lo = std::min(cols, rows);
+    if (sc->mismatch > sc->match) { set_err("mismatch score must not exceed the match score"); return SW_EINVAL; }
+    const int64_t lo = std::min(gc, gr);
+    // largest G-space magnitude: H <= match*min(dims) plus -gap*(row+col); the per-step constants ride on top
     const int64_t gmax = (int64_t)sc->match * lo + (int64_t)(-sc->gap) * (rows + cols + 2);
-    if (gmax >= (1ll << 31) || (int64_t)sc->match * lo >= (1ll << 24)) {
+    const int64_t step = std::max<int64_t>(std::llabs((int64_t)sc->mismatch), (int64_t)sc->match) + 2 * (int64_t)(-sc->gap);
+    if (gmax + step >= (1ll << 31) || step >= (1ll << 24) || (int64_t)sc->match * lo >= (1ll << 24)) {
         set_err("scores too large for this problem size (32-bit cell / 24-bit arg-max key)");
         return SW_EINVAL;
     }
@@ -134,18 +159,44 @@ static int check_dims(int64_t cols, int64_t rows, const sw_scores* sc) {
 // batch of independent problems.
 struct FillJob {
     const char* d_a; int64_t cols; const char* d_b; int64_t rows;
-    void* d_H; int h_elem_bytes; int32_t* d_P; int64_t stride;
+    void* d_H; int h_elem_bytes; void* d_P; int64_t stride;     // d_H / d_P may be NULL: that matrix is not written
     const int32_t* d_top; const int32_t* d_left; int32_t* d_right;
     int64_t npairs; int64_t a_pstride, b_pstride, hp_pstride;
     unsigned long long* d_keys;   // npairs packed arg-max keys (device)
     int p_elem_bytes = 4;         // 4: int32 P (reference layout); 1: compact int8 P
+    // band-resident launch (sw_fill_band_device)
+    const unsigned long long* d_top_gran = nullptr; unsigned long long* d_bot_gran = nullptr; unsigned int* d_bot_done = nullptr;
+    unsigned int top_tag = 0, bot_tag = 0;
+    int reserve_cus = 0;          // CUs left free for other kernels (halo transfers)
+    bool concurrent = false;      // do not order this launch behind fills on other streams (the caller partitions the CUs)
+};
+
+// called with g_dev[device].mu held: make `stream` wait for the fills enqueued on other streams of this device
+static int order_after_previous_fill(DevState& d, hipStream_t stream, bool allow_concurrent) {
+    if (d.any && d.last_stream != stream && !allow_concurrent) {
+        if (!d.ev) HIP_TRY(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(d.ev, d.last_stream));
+        HIP_TRY(hipStreamWaitEvent(stream, d.ev, 0));
+    }
+    d.any = true;
+    d.last_stream = stream;
+    return SW_OK;
+}
+
+struct DevOrder {   // RAII: device lock + stream ordering for one fill call
+    std::unique_lock<std::mutex> lk;
+    int rc;
+    DevOrder(sw_ctx* c, hipStream_t stream, bool concurrent) : lk(g_dev[c->device & 63].mu) {
+        rc = order_after_previous_fill(g_dev[c->device & 63], stream, concurrent);
+    }
 };
 
 static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStream_t stream) {
     const int64_t cols = j.cols, rows = j.rows;
     const bool systolic = (c->opt_engine == 0);
-    const bool tile_features = j.d_left || j.d_right || j.stride != cols + 1 || j.npairs != 1 || !j.d_H;
-    if (!systolic && tile_features) { set_err("tiles / batches need the systolic engine (engine 0)"); return SW_EINVAL; }
+    const bool tile_features = j.d_left || j.d_right || j.stride != cols + 1 || j.npairs != 1 || !j.d_H || !j.d_P || j.d_top_gran || j.d_bot_gran;
+    if (!systolic && tile_features) { set_err("tiles / batches / bands / matrix-less fills need the systolic engine (engine 0)"); return SW_EINVAL; }
+    // (the caller holds the device lock and has ordered `stream` behind earlier fills: DevOrder)
     const int64_t S = systolic ? (cols + 62) / 63 : (cols + 63) / 64;
     if (((uintptr_t)j.d_b & 15) != 0 || (j.b_pstride & 15) != 0) { set_err("d_b (and the batch stride of b) must be 16-byte aligned"); return SW_EINVAL; }
     const size_t need = (size_t)S * (size_t)(rows + 1) * (size_t)j.npairs;
@@ -165,7 +216,9 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
     swk::FillParams p;
     memset(&p, 0, sizeof p);
     p.cols = cols; p.rows = rows; p.M = j.stride;
-    p.H = j.d_H; p.P = j.d_P; p.top = j.d_top; p.left = j.d_left; p.right = j.d_right;
+    p.H = j.d_H; p.P = (int32_t*)j.d_P; p.top = j.d_top; p.left = j.d_left; p.right = j.d_right;
+    p.top_gran = j.d_top_gran; p.bot_gran = j.d_bot_gran; p.bot_done = j.d_bot_done; p.top_tag = j.top_tag; p.bot_tag = j.bot_tag;
+    p.top_wait_ticks = (unsigned)std::min<int64_t>(0x7fffffff, c->opt_band_wait_ms * 100000 >> 10);
     p.mm = sc->match - 2 * sc->gap; p.xm = sc->mismatch - 2 * sc->gap; p.ngap = -sc->gap;
     p.edge = c->d_edge; p.tag_base = c->epoch << 20;
     p.result_key = j.d_keys; p.abort_flag = (unsigned int*)(c->d_key + 1);
@@ -177,9 +230,9 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
     p.store_nt = c->opt_store_policy == 2 || (c->opt_store_policy == 0 && (double)cols * (double)rows * (double)j.npairs <= 6.0e8);
     p.xcd_order = (int)c->opt_xcd_order;
     p.dbg = (unsigned long long*)(uintptr_t)c->opt_dbg_ptr;
-    p.npairs = (int)j.npairs; p.store_hp = j.d_H ? 1 : 0;
+    p.npairs = (int)j.npairs; p.store_hp = (j.d_H || j.d_P) ? 1 : 0;
     p.p_bytes = j.p_elem_bytes;
-    if (j.p_elem_bytes == 1 && (!systolic || j.npairs != 1)) { set_err("compact (int8) P needs the systolic engine and a single pair"); return SW_EINVAL; }
+    if (j.p_elem_bytes == 1 && !systolic) { set_err("compact (int8) P needs the systolic engine"); return SW_EINVAL; }
     p.a_pstride = j.a_pstride; p.b_pstride = j.b_pstride; p.hp_pstride = j.hp_pstride;
     p.edge_pstride = S * (rows + 1);
     const unsigned char* ua = (const unsigned char*)j.d_a;
@@ -206,23 +259,30 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         unsigned short* d_cb16 = (unsigned short*)(c->d_cb + ((c->cb_cap + 15) / 16) * 16);
         hipLaunchKernelGGL(swk::sw_pad_b, dim3((unsigned)((per + 255) / 256), (unsigned)j.npairs), dim3(256), 0, stream, ub, rows, bfront,
                            j.b_pstride, c->d_cb, d_cb16, per);
-        const bool fast = (j.d_top == nullptr) && (sc->mismatch <= 0) && !(c->opt_debug & 4);
+        const bool fast = (j.d_top == nullptr) && (j.d_top_gran == nullptr) && (sc->mismatch <= 0) && !(c->opt_debug & 4);
         p.phi_base = fast ? (int)S - 1 : -1;
         p.bfront = (int)bfront;
         p.bpad16 = d_cb16;
         p.bpad_pstride = per;
         const int64_t ngroups = ((S + NS - 1) / NS) * j.npairs;
-        const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : (int64_t)c->num_cus;
-        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ngroups, maxb));
-        c->last_grid = grid; c->last_strips = S;
+        const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : std::max<int64_t>(8, (int64_t)c->num_cus - j.reserve_cus);
+        int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ngroups, maxb));
         const int base_waves = NS * (1 + NC) + 2;
         const int extra_imp = (NS == 1) ? (int)std::max<int64_t>(0, std::min<int64_t>(c->opt_importers - 1, 12 - base_waves)) : 0;
         const int threads = 64 * (base_waves + extra_imp);
         const unsigned char* cbp = c->d_cb;
         bool launched = false;
+        // every workgroup of the grid must be resident (they wait for each other): never launch more than the occupancy
+        // query admits on this device
 #define SW_LAUNCH(ns, nc)                                                                                                        \
     if (!launched && NS == ns && NC == nc) {                                                                                      \
         launched = true;                                                                                                          \
+        int per_cu = 0;                                                                                                           \
+        if (j.h_elem_bytes == 4) HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, swk::sw_systolic<int32_t, ns, nc>, threads, 0)); \
+        else HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, swk::sw_systolic<int64_t, ns, nc>, threads, 0));     \
+        if (per_cu < 1) { set_err("the fill kernel does not fit a CU on this device"); return SW_EDEVICE; }                      \
+        grid = (int)std::min<int64_t>(grid, (int64_t)per_cu * c->num_cus);                                                        \
+        c->last_grid = grid; c->last_strips = S;                                                                                  \
         if (j.h_elem_bytes == 4)                                                                                                  \
             hipLaunchKernelGGL((swk::sw_systolic<int32_t, ns, nc>), dim3(grid), dim3(threads), 0, stream, ua, ub, cbp, p);       \
         else                                                                                                                      \
@@ -245,32 +305,35 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
     return SW_OK;
 }
 
-static int fill_tile_impl(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
-                          void* d_H, int h_elem_bytes, void* d_P, int p_elem_bytes, int64_t row_stride, const int32_t* d_top,
-                          const int32_t* d_left, int32_t* d_right, sw_result* d_result, void* stream_) {
-    static const sw_scores kDefault = {3, -3, -2};  // serial_smithW.c:59-61
-    const sw_scores* sc = scores ? scores : &kDefault;
-    if (!c || !d_H || !d_P || !d_result || (h_elem_bytes != 4 && h_elem_bytes != 8) || (p_elem_bytes != 4 && p_elem_bytes != 1) ||
-        row_stride < cols + 1) {
-        set_err("sw_fill_tile_device: bad argument");
+static const sw_scores kDefaultScores = {3, -3, -2};  // serial_smithW.c:59-61
+
+// one matrix / tile / band: validation, empty shapes, launch, finalize
+static int fill_one(sw_ctx* c, const sw_scores* scores, FillJob j, int64_t gcols, int64_t grows, sw_result* d_result, void* stream_,
+                    const char* who) {
+    const sw_scores* sc = scores ? scores : &kDefaultScores;
+    const int64_t cols = j.cols, rows = j.rows;
+    if (!c || !d_result || (j.h_elem_bytes != 4 && j.h_elem_bytes != 8) || (j.p_elem_bytes != 4 && j.p_elem_bytes != 1) ||
+        j.stride < cols + 1) {
+        set_err("%s: bad argument", who);
         return SW_EINVAL;
     }
-    if (int rc = check_dims(cols, rows, sc)) return rc;
-    if ((cols > 0 && !d_a) || (rows > 0 && !d_b)) { set_err("sw_fill_tile_device: NULL sequence"); return SW_EINVAL; }
+    if (int rc = check_dims(cols, rows, sc, gcols, grows)) return rc;
+    if ((cols > 0 && !j.d_a) || (rows > 0 && !j.d_b)) { set_err("%s: NULL sequence", who); return SW_EINVAL; }
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(c->device));
+    DevOrder order(c, stream, j.concurrent);
+    if (order.rc) return order.rc;
     HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream));
+    j.d_keys = c->d_key;
     if (cols == 0 || rows == 0) {
         // no interior cell: H (= halo row / zero column) and P are all boundary
-        if (row_stride != cols + 1 || d_left || d_right) { set_err("empty tiles are not supported"); return SW_EINVAL; }
+        if (j.stride != cols + 1 || j.d_left || j.d_right || j.d_top_gran || j.d_bot_gran) { set_err("%s: empty tiles / bands are not supported", who); return SW_EINVAL; }
         const int64_t M = cols + 1;
-        HIP_TRY(hipMemsetAsync(d_H, 0, (size_t)(M * (rows + 1)) * h_elem_bytes, stream));
-        HIP_TRY(hipMemsetAsync(d_P, 0, (size_t)(M * (rows + 1)) * p_elem_bytes, stream));
-        if (d_top && h_elem_bytes == 4) HIP_TRY(hipMemcpyAsync(d_H, d_top, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
-        if (d_top && h_elem_bytes == 8) { set_err("top halo with an empty int64 band is unsupported"); return SW_EINVAL; }
+        if (j.d_H) HIP_TRY(hipMemsetAsync(j.d_H, 0, (size_t)(M * (rows + 1)) * j.h_elem_bytes, stream));
+        if (j.d_P) HIP_TRY(hipMemsetAsync(j.d_P, 0, (size_t)(M * (rows + 1)) * j.p_elem_bytes, stream));
+        if (j.d_H && j.d_top && j.h_elem_bytes == 4) HIP_TRY(hipMemcpyAsync(j.d_H, j.d_top, (size_t)M * 4, hipMemcpyDeviceToDevice, stream));
+        if (j.d_H && j.d_top && j.h_elem_bytes == 8) { set_err("top halo with an empty int64 band is unsupported"); return SW_EINVAL; }
     } else {
-        FillJob j = {d_a, cols, d_b, rows, d_H, h_elem_bytes, (int32_t*)d_P, row_stride, d_top, d_left, d_right, 1, 0, 0, 0, c->d_key};
-        j.p_elem_bytes = p_elem_bytes;
         if (int rc = launch_fill(c, sc, j, stream)) return rc;
     }
     hipLaunchKernelGGL(swk::sw_finalize, dim3(1), dim3(64), 0, stream, c->d_key, (const unsigned int*)(c->d_key + 1), d_result, 1);
@@ -278,32 +341,62 @@ static int fill_tile_impl(sw_ctx* c, const char* d_a, int64_t cols, const char* 
     return SW_OK;
 }
 
+static FillJob make_job(const char* d_a, int64_t cols, const char* d_b, int64_t rows, void* d_H, int h_elem_bytes, void* d_P, int p_elem_bytes,
+                        int64_t row_stride, const int32_t* d_top, const int32_t* d_left, int32_t* d_right) {
+    FillJob j = {d_a, cols, d_b, rows, d_H, h_elem_bytes, d_P, row_stride, d_top, d_left, d_right, 1, 0, 0, 0, nullptr};
+    j.p_elem_bytes = p_elem_bytes;
+    return j;
+}
+
 int sw_fill_tile_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
                         void* d_H, int h_elem_bytes, int32_t* d_P, int64_t row_stride, const int32_t* d_top,
                         const int32_t* d_left, int32_t* d_right, sw_result* d_result, void* stream_) {
-    return fill_tile_impl(c, d_a, cols, d_b, rows, scores, d_H, h_elem_bytes, d_P, 4, row_stride, d_top, d_left, d_right, d_result, stream_);
+    if (!d_H || !d_P) { set_err("sw_fill_tile_device: bad argument"); return SW_EINVAL; }
+    return fill_one(c, scores, make_job(d_a, cols, d_b, rows, d_H, h_elem_bytes, d_P, 4, row_stride, d_top, d_left, d_right), -1, -1, d_result,
+                    stream_, "sw_fill_tile_device");
 }
 
 int sw_fill_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
                    void* d_H, int h_elem_bytes, int32_t* d_P, const int32_t* d_top, sw_result* d_result, void* stream_) {
-    return fill_tile_impl(c, d_a, cols, d_b, rows, scores, d_H, h_elem_bytes, d_P, 4, cols + 1, d_top, nullptr, nullptr, d_result, stream_);
+    if (!d_H || !d_P) { set_err("sw_fill_device: bad argument"); return SW_EINVAL; }
+    return fill_one(c, scores, make_job(d_a, cols, d_b, rows, d_H, h_elem_bytes, d_P, 4, cols + 1, d_top, nullptr, nullptr), -1, -1, d_result,
+                    stream_, "sw_fill_device");
 }
 
-// compact P: one byte per predecessor code (same values 0..3, -1..-3 after the traceback), SURVEY.md 8f-2
+// compact P (one byte per predecessor code, same values 0..3, -1..-3 after the traceback) and matrix-less fills
+// (d_H and/or d_P NULL: that matrix is not written; arg-max stays exact), SURVEY.md 8f-2
 int sw_fill_device_ex(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
                       void* d_H, int h_elem_bytes, void* d_P, int p_elem_bytes, const int32_t* d_top, sw_result* d_result,
                       void* stream_) {
-    return fill_tile_impl(c, d_a, cols, d_b, rows, scores, d_H, h_elem_bytes, d_P, p_elem_bytes, cols + 1, d_top, nullptr, nullptr, d_result, stream_);
+    return fill_one(c, scores, make_job(d_a, cols, d_b, rows, d_H, h_elem_bytes, d_P, p_elem_bytes, cols + 1, d_top, nullptr, nullptr), -1, -1,
+                    d_result, stream_, "sw_fill_device_ex");
+}
+
+// One row band of a (total_rows+1) x (cols+1) matrix as ONE persistent launch (multi-GPU): the halo row
+// arrives and leaves as {tag, H} granules while the kernel runs.
+int sw_fill_band_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, int64_t total_rows,
+                        const sw_scores* scores, void* d_H, int h_elem_bytes, void* d_P, int p_elem_bytes,
+                        const uint64_t* d_top_gran, uint32_t top_tag, uint64_t* d_bot_gran, uint32_t bot_tag, uint32_t* d_bot_done,
+                        int reserve_cus, int concurrent, sw_result* d_result, void* stream_) {
+    if ((d_top_gran && top_tag == 0) || (d_bot_gran && bot_tag == 0) || (d_bot_done && !d_bot_gran) || reserve_cus < 0 || total_rows < rows) {
+        set_err("sw_fill_band_device: bad argument");
+        return SW_EINVAL;
+    }
+    if (c && c->opt_engine != 0) { set_err("sw_fill_band_device needs the systolic engine"); return SW_EINVAL; }
+    FillJob j = make_job(d_a, cols, d_b, rows, d_H, h_elem_bytes, d_P, p_elem_bytes, cols + 1, nullptr, nullptr, nullptr);
+    j.d_top_gran = (const unsigned long long*)d_top_gran; j.d_bot_gran = (unsigned long long*)d_bot_gran; j.d_bot_done = d_bot_done;
+    j.top_tag = top_tag; j.bot_tag = bot_tag; j.reserve_cus = reserve_cus; j.concurrent = concurrent != 0;
+    return fill_one(c, scores, j, cols, total_rows, d_result, stream_, "sw_fill_band_device");
 }
 
 // BASELINE config 5: npairs independent cols x rows problems; pair k reads a at d_a + k*a_stride, b at d_b + k*b_stride.
-// d_H / d_P may both be NULL (score-only: max_score exact, max_pos = first row of the 16-row block that holds it).
-int sw_batch_device(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t cols, const char* d_b, int64_t b_stride, int64_t rows,
-                    int64_t npairs, const sw_scores* scores, int32_t* d_H, int32_t* d_P, sw_result* d_results, void* stream_) {
-    static const sw_scores kDefault = {3, -3, -2};
-    const sw_scores* sc = scores ? scores : &kDefault;
-    if (!c || !d_a || !d_b || !d_results || npairs <= 0 || cols <= 0 || rows <= 0 || ((d_H == nullptr) != (d_P == nullptr)) ||
-        a_stride < cols || b_stride < rows) {
+// d_H and/or d_P may be NULL (that matrix is not written); the arg-max is exact in every mode.
+int sw_batch_device_ex(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t cols, const char* d_b, int64_t b_stride, int64_t rows,
+                       int64_t npairs, const sw_scores* scores, int32_t* d_H, void* d_P, int p_elem_bytes, sw_result* d_results,
+                       void* stream_) {
+    const sw_scores* sc = scores ? scores : &kDefaultScores;
+    if (!c || !d_a || !d_b || !d_results || npairs <= 0 || cols <= 0 || rows <= 0 || a_stride < cols || b_stride < rows ||
+        (p_elem_bytes != 4 && p_elem_bytes != 1)) {
         set_err("sw_batch_device: bad argument");
         return SW_EINVAL;
     }
@@ -311,6 +404,8 @@ int sw_batch_device(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t cols, 
     if (int rc = check_dims(cols, rows, sc)) return rc;
     hipStream_t stream = (hipStream_t)stream_;
     HIP_TRY(hipSetDevice(c->device));
+    DevOrder order(c, stream, false);
+    if (order.rc) return order.rc;
     const int64_t chunk_max = 4096;   // pairs per launch: bounds the edge / padded-b workspace
     if ((size_t)std::min(npairs, chunk_max) > c->keys_cap) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -324,7 +419,9 @@ int sw_batch_device(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t cols, 
         const int64_t n = std::min(chunk_max, npairs - k0);
         HIP_TRY(hipMemsetAsync(c->d_keys, 0, (size_t)n * 8, stream));
         FillJob j = {d_a + k0 * a_stride, cols, d_b + k0 * b_stride, rows, d_H ? (void*)(d_H + k0 * cells) : nullptr, 4,
-                     d_P ? d_P + k0 * cells : nullptr, cols + 1, nullptr, nullptr, nullptr, n, a_stride, b_stride, cells, c->d_keys};
+                     d_P ? (void*)((char*)d_P + k0 * cells * p_elem_bytes) : nullptr, cols + 1, nullptr, nullptr, nullptr, n, a_stride, b_stride,
+                     cells, c->d_keys};
+        j.p_elem_bytes = p_elem_bytes;
         if (int rc = launch_fill(c, sc, j, stream)) return rc;
         hipLaunchKernelGGL(swk::sw_finalize, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, c->d_keys,
                            (const unsigned int*)(c->d_key + 1), d_results + k0, (int)n);
@@ -332,10 +429,36 @@ int sw_batch_device(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t cols, 
     }
     return SW_OK;
 }
+int sw_batch_device(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t cols, const char* d_b, int64_t b_stride, int64_t rows,
+                    int64_t npairs, const sw_scores* scores, int32_t* d_H, int32_t* d_P, sw_result* d_results, void* stream_) {
+    return sw_batch_device_ex(c, d_a, a_stride, cols, d_b, b_stride, rows, npairs, scores, d_H, d_P, 4, d_results, stream_);
+}
+
+// backtrack() of every pair of a batch (serial_smithW.c:262-277 per pair): one lane per pair walks its P from
+// d_results[k].max_pos, negates the path and sets d_results[k].path_len; d_paths (optional) receives the visited
+// pair-local indices, path_cap per pair.
+int sw_batch_traceback_device(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t npairs, int64_t* d_paths,
+                              int64_t path_cap, sw_result* d_results, void* stream_) {
+    if (!c || !d_P || !d_results || cols < 0 || rows < 0 || npairs <= 0 || (p_elem_bytes != 4 && p_elem_bytes != 1) || (d_paths && path_cap <= 0)) {
+        set_err("sw_batch_traceback_device: bad argument");
+        return SW_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t cells = (cols + 1) * (rows + 1);
+    const dim3 grid((unsigned)((npairs + 63) / 64)), block(64);
+    if (p_elem_bytes == 4)
+        hipLaunchKernelGGL(swk::sw_traceback_batch<int32_t>, grid, block, 0, (hipStream_t)stream_, (int32_t*)d_P, cols + 1, cells, npairs, d_paths,
+                           d_paths ? path_cap : 0, d_results);
+    else
+        hipLaunchKernelGGL(swk::sw_traceback_batch<signed char>, grid, block, 0, (hipStream_t)stream_, (signed char*)d_P, cols + 1, cells, npairs,
+                           d_paths, d_paths ? path_cap : 0, d_results);
+    HIP_TRY(hipGetLastError());
+    return SW_OK;
+}
 
 int sw_fill_host(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t rows, const sw_scores* scores,
                  int32_t* H, int32_t* P, sw_result* result) {
-    if (!c || !result) { set_err("sw_fill_host: bad argument"); return SW_EINVAL; }
+    if (!c || !result || cols < 0 || rows < 0 || (cols > 0 && !a) || (rows > 0 && !b)) { set_err("sw_fill_host: bad argument"); return SW_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     const size_t cells = (size_t)(cols + 1) * (size_t)(rows + 1);
     char *d_a = nullptr, *d_b = nullptr; int32_t *d_H = nullptr, *d_P = nullptr; sw_result* d_r = nullptr;
@@ -346,19 +469,22 @@ int sw_fill_host(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t 
         hipMalloc((void**)&d_r, sizeof(sw_result)) != hipSuccess) {
         cleanup(); set_err("sw_fill_host: device allocation failed"); return SW_ENOMEM;
     }
-    if (cols) (void)hipMemcpy(d_a, a, (size_t)cols, hipMemcpyHostToDevice);
-    if (rows) (void)hipMemcpy(d_b, b, (size_t)rows, hipMemcpyHostToDevice);
-    rc = sw_fill_device(c, d_a, cols, d_b, rows, scores, d_H, 4, d_P, nullptr, d_r, nullptr);
+    auto copy = [&](void* dst, const void* src, size_t n, hipMemcpyKind kind, const char* what) {
+        if (rc != SW_OK || n == 0) return;
+        const hipError_t e = hipMemcpy(dst, src, n, kind);
+        if (e != hipSuccess) { set_err("sw_fill_host: copying %s failed: %s", what, hipGetErrorString(e)); rc = SW_EDEVICE; }
+    };
+    copy(d_a, a, (size_t)cols, hipMemcpyHostToDevice, "a");
+    copy(d_b, b, (size_t)rows, hipMemcpyHostToDevice, "b");
+    if (rc == SW_OK) rc = sw_fill_device(c, d_a, cols, d_b, rows, scores, d_H, 4, d_P, nullptr, d_r, nullptr);
     if (rc == SW_OK) {
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) { set_err("fill kernel failed: %s", hipGetErrorString(e)); rc = SW_EDEVICE; }
     }
-    if (rc == SW_OK) {
-        (void)hipMemcpy(result, d_r, sizeof(sw_result), hipMemcpyDeviceToHost);
-        if (result->path_len < 0) { set_err("fill kernel: hand-off wait timed out"); rc = SW_ETIMEOUT; }
-        if (H) (void)hipMemcpy(H, d_H, cells * 4, hipMemcpyDeviceToHost);
-        if (P) (void)hipMemcpy(P, d_P, cells * 4, hipMemcpyDeviceToHost);
-    }
+    copy(result, d_r, sizeof(sw_result), hipMemcpyDeviceToHost, "the result");
+    if (rc == SW_OK && result->path_len < 0) { set_err("fill kernel: hand-off wait timed out"); rc = SW_ETIMEOUT; }
+    if (H) copy(H, d_H, cells * 4, hipMemcpyDeviceToHost, "H");
+    if (P) copy(P, d_P, cells * 4, hipMemcpyDeviceToHost, "P");
     cleanup();
     return rc;
 }

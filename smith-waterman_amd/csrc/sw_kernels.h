@@ -19,7 +19,7 @@ struct FillParams {
     const int32_t* left;       // systolic: optional halo column (rows+1 H values of the column left of the tile), NULL = zeros
     int32_t* right;            // systolic: optional output, H of the tile's last column (rows+1)
     int npairs;                // systolic: independent problems in this launch (batch), 1 otherwise
-    int store_hp;              // systolic: 0 = score-only (H/P are not written)
+    int store_hp;              // (unused; H / P are written when their pointers are non-NULL)
     int64_t a_pstride, b_pstride, bpad_pstride, hp_pstride, edge_pstride;  // per-pair strides (elements)
     int32_t mm, xm, ngap;      // match-2*gap, mismatch-2*gap, -gap  (G-space constants)
     unsigned long long* edge;  // [nstrips][rows+1] {tag,value} granules
@@ -36,6 +36,13 @@ struct FillParams {
     int pace_ps;               // systolic: strip 0 releases one row per pace_ps picoseconds (0 = unpaced)
     int debug_flags;           // bit0: drop the H/P stores (timing experiments only)
     int nstrips;               // strip_scan: ceil(cols/64); systolic: ceil(cols/63)
+    // band-resident launch (systolic; multi-GPU row bands): the halo row arrives / leaves as 8-byte
+    // {tag, H value} granules, one per column, while the kernel runs
+    const unsigned long long* top_gran;  // cols+1 granules of the row above (polled per strip), or NULL
+    unsigned long long* bot_gran;        // cols+1 granules of the band's last row (written per strip), or NULL
+    unsigned int* bot_done;              // optional [nstrips]: set to bot_tag (system scope, after a release) once the strip's bottom granules are written
+    unsigned int top_tag, bot_tag;
+    unsigned int top_wait_ticks;         // patience of the top-halo poll in 100 MHz ticks / 2^10
 };
 
 template <typename HT, int B>
@@ -46,6 +53,8 @@ __global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, in
 __global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res, int n);
 template <typename PT>
 __global__ void sw_traceback(PT* P, int64_t M, int64_t maxPos, int64_t* path, int64_t cap, sw_result* res);
+template <typename PT>
+__global__ void sw_traceback_batch(PT* P, int64_t M, int64_t pstride, int64_t npairs, int64_t* paths, int64_t cap, sw_result* res);
 template <typename T> __global__ void sw_row_checksums(const T* X, int64_t m, unsigned long long* cs);
 
 }  // namespace swk

@@ -289,6 +289,30 @@ __global__ void sw_traceback(PT* __restrict__ P, int64_t M, int64_t maxPos, int6
     res->path_len = len;
 }
 
+// backtrack() for a batch of independent problems (BASELINE config 5): one lane per pair walks that pair's P from
+// res[k].max_pos (pair-local index), negates the path, optionally records it, and sets res[k].path_len.
+template <typename PT>
+__global__ void sw_traceback_batch(PT* __restrict__ P, int64_t M, int64_t pstride, int64_t npairs, int64_t* __restrict__ paths,
+                                   int64_t cap, sw_result* __restrict__ res) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= npairs || res[k].path_len < 0) return;
+    PT* Pk = P + k * pstride;
+    int64_t* path = paths ? paths + k * cap : nullptr;
+    int64_t len = 0, pos = res[k].max_pos;
+    int pr = Pk[pos];
+    while (pr > 0) {
+        const int64_t pred = (pr == 3) ? pos - M - 1 : (pr == 1) ? pos - M : pos - 1;
+        Pk[pos] = (PT)-pr;
+        if (path && len < cap) path[len] = pos;
+        ++len;
+        pos = pred;
+        pr = Pk[pos];
+    }
+    res[k].path_len = len;
+}
+template __global__ void sw_traceback_batch<int32_t>(int32_t*, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*);
+template __global__ void sw_traceback_batch<signed char>(signed char*, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*);
+
 // cs[i] = sum_j (u64)(u32)X[i][j] * ((j+1) * 0x9E3779B97F4A7C15); one block per row
 template <typename T>
 __global__ void __launch_bounds__(256) sw_row_checksums(const T* __restrict__ X, int64_t m, u64* __restrict__ cs) {

@@ -66,6 +66,7 @@ struct SysLds {
     int halo_ready;   // imported halo: every local step (strip s0's numbering) < halo_ready is in halo[]
     int exp_done;     // exported edge rows: every row <= exp_done is in HBM
     int never;        // INT_MAX
+    int topv[NS][64]; // band-resident launch: this group's segment of the halo row (H values), polled from top_gran
 };
 
 // counters are wave-uniform by construction; readfirstlane makes that provable, so every poll loop
@@ -652,14 +653,42 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
         p.edge = p0.edge + pair * p0.edge_pstride;
         p.result_key = p0.result_key + pair;
         p.H = p0.H ? (void*)((char*)p0.H + pair * p0.hp_pstride * (int64_t)sizeof(HT)) : nullptr;
-        p.P = p0.P ? p0.P + pair * p0.hp_pstride : nullptr;
+        p.P = p0.P ? (int32_t*)((char*)p0.P + pair * p0.hp_pstride * (int64_t)p0.p_bytes) : nullptr;
         if (threadIdx.x < NS) lds.prod_u[threadIdx.x] = 0;
         if (threadIdx.x < NS * 4) lds.cons_blk[threadIdx.x / 4][threadIdx.x % 4] = ((int)(threadIdx.x % 4) < NC) ? -1 : 0x7fffffff;
         if (threadIdx.x == 0) { lds.halo_ready = 1; lds.exp_done = 0; lds.never = 0x7fffffff; }
-        __syncthreads();
-
         const int s0 = grp * NS;
         const int nact = min(NS, p.nstrips - s0);  // active strips of this group
+        const bool has_top = (p.top != nullptr) || (p.top_gran != nullptr);
+        if (p.top_gran && wave < NS) {
+            // band-resident launch: this strip's 64 columns of the row above, {tag, value} granules written by whoever
+            // receives the neighbour band's last row (any order, any time): the data is its own flag
+            const int64_t jt = (int64_t)(s0 + wave) * SY_W + lane;
+            const bool want = (wave < nact) && jt <= p.cols;
+            u64 gr = 0;
+            uint64_t t0 = 0;
+            unsigned n = 0;
+            for (;;) {
+                if (want) gr = __hip_atomic_load((gu64*)(p.top_gran + jt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const bool ok = !want || (u32)(gr >> 32) == p.top_tag;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                __builtin_amdgcn_s_sleep(8);
+                if ((++n & 63u) == 0) {
+                    const uint64_t now = __builtin_amdgcn_s_memrealtime();
+                    if (t0 == 0) t0 = now;
+                    if (((now - t0) >> 10) > (uint64_t)p.top_wait_ticks)
+                        __hip_atomic_store((gu32*)p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32*)p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) break;
+                }
+            }
+            lds.topv[wave][lane] = (int)(u32)gr;
+        }
+        __syncthreads();
+        if (p.top_gran && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32*)p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
+        // H of the halo row above column (strip ls, lane l)
+        auto top_at = [&](int ls_, int lane_, int64_t j_) -> int {
+            return p.top_gran ? lds.topv[ls_][lane_] : (p.top ? p.top[j_] : 0);
+        };
 
         // Role of each wave.  Waves are dealt to the four SIMDs cyclically, so waves w, w+4, w+8 share a
         // SIMD: with NS == 2 the two mostly-sleeping helper waves take slots 4 and 5, i.e. the SIMDs of the
@@ -678,13 +707,13 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
             // ================================ producer ================================
             const int ls = wave, s = s0 + ls;
             asm volatile("; SW_PRODUCER_PATH_BEGIN ");
-            if (ls < nact) {
+            if (ls < nact && !((p.debug_flags & 8) && s == 1)) {   // debug bit 3: strip 1 never runs (tests the abort path)
                 const int phi = phi_of(s, phib);
                 const int UT = u_total(s);
                 const u32 j = (u32)s * SY_W + (u32)lane;
                 const bool jvalid = (int64_t)j <= p.cols;
                 const u32 a_l = (lane >= 1 && jvalid) ? (u32)seq_a[j - 1] : (u32)SY_ASENT;
-                const u32 G0v = jvalid ? (u32)((p.top ? p.top[j] : 0) + ngap * (int)j) : 0u;  // row 0 in G-space
+                const u32 G0v = jvalid ? (u32)(top_at(ls, lane, j) + ngap * (int)j) : 0u;  // row 0 in G-space
                 const u32 mm_v = (u32)mm, xm_v = (u32)xm, ngap_v = (u32)ngap;
                 const bool lefthalo = (ls == 0);         // halo comes from the import ring
                 const bool has_right = (ls + 1 < nact);  // another producer reads my lane-63 column
@@ -815,25 +844,31 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 const bool jvalid = (int64_t)j <= p.cols;
                 // lane 0 of strip 0 is the tile's own column 0 only for a whole matrix (left == NULL)
                 const bool cell_ok = jvalid && (lane >= 1 || (s == 0 && p.left == nullptr));
-                const bool store_ok = cell_ok && p.store_hp && !(p.debug_flags & 1);
+                const bool store_h = cell_ok && p.H != nullptr && !(p.debug_flags & 1);
+                const bool store_p = cell_ok && p.P != nullptr && !(p.debug_flags & 1);
                 const bool last_strip = (s + 1 == p.nstrips);
                 const int lc = (int)p.cols - s * SY_W;          // lane of the tile's last column (in the last strip)
                 const bool right_strip = last_strip && p.right != nullptr;   // this strip also returns the tile's right edge column
                 const bool right_lane = right_strip && lane == lc;
-                const u32 voffH = store_ok ? j * (u32)sizeof(HT) : SY_OOB;
+                const u32 voffH = store_h ? j * (u32)sizeof(HT) : SY_OOB;
                 const bool p8 = (p.p_bytes == 1);                 // compact predecessor matrix: one byte per cell
-                const u32 voffP = store_ok ? j * (p8 ? 1u : 4u) : SY_OOB;
+                const u32 voffP = store_p ? j * (p8 ? 1u : 4u) : SY_OOB;
                 const int a_l = (lane >= 1 && jvalid) ? (int)seq_a[j - 1] : SY_ASENT;
                 const int cz = ngap * (int)j;
-                const int G0v = jvalid ? (p.top ? p.top[j] : 0) + cz : 0;
+                const int topj = jvalid ? top_at(ls, lane, j) : 0;
+                const int G0v = topj + (jvalid ? cz : 0);
                 HT* H = (HT*)p.H;
                 int32_t* P = p.P;
-                if (ci == 0 && store_ok) {  // row 0: the halo row itself (P of a row owned by the tile above is left alone)
-                    H[j] = (HT)(p.top ? p.top[j] : 0);
-                    if (!p.top) { if (p8) ((signed char*)P)[j] = 0; else P[j] = 0; }
+                if (ci == 0) {  // row 0: the halo row itself (P of a row owned by the tile above is left alone)
+                    if (store_h) H[j] = (HT)topj;
+                    if (store_p && !has_top) { if (p8) ((signed char*)P)[j] = 0; else P[j] = 0; }
                 }
-                if (ci == 0 && right_lane) p.right[0] = p.top ? p.top[j] : 0;
-                int bestv = 0, bestblk = 0;   // arg-max: best value and the first of MY blocks that reached it
+                if (ci == 0 && right_lane) p.right[0] = topj;
+                // arg-max: best value of my column and where it first occurred.  With H in HBM only the 16-row block is
+                // noted and its exact row is re-read at the end (free inside the loop); without H (score-only, P-only)
+                // the row is resolved on the spot from the ring values, but only when some lane beats the wave's best so far
+                int bestv = 0, bestblk = 0, bestrow = 0, wbest = 0;
+                const bool reread = (p.H != nullptr);
                 const u32 a_lu = (u32)a_l, mm_v = (u32)mm, xm_v = (u32)xm, ngap_v = (u32)ngap;
                 const int nblk = (rows + SY_U - 1) / SY_U;
                 const u32* myring = (const u32*)&lds.ring[ls][lane * SY_LSTR];
@@ -924,9 +959,40 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                             blkmax = (u32)max((int)blkmax, h);
                         }
                     }
-                    if ((int)blkmax > bestv) { bestv = (int)blkmax; bestblk = q; }
+                    if (reread) {
+                        if ((int)blkmax > bestv) { bestv = (int)blkmax; bestblk = q; }
+                    } else {
+                        const int bm = cell_ok ? (int)blkmax : 0;
+                        if (__builtin_amdgcn_ballot_w64(bm > wbest) != 0) {
+                            if (bm > bestv) {
+                                bestv = bm;
+                                int row = r0;
+                                sfor<0, SY_U>([&](auto K) {
+                                    constexpr int k = SY_U - 1 - K.value;   // descending: the lowest row wins
+                                    if (k < nb && (int)gv[k + 1] - (cz + ngap * (r0 + k)) == bm) row = r0 + k;
+                                });
+                                bestrow = row;
+                            }
+                            int v = bestv;
+                            for (int off = 32; off; off >>= 1) v = max(v, __shfl_xor(v, off));
+                            wbest = __builtin_amdgcn_readfirstlane(v);
+                        }
+                    }
                     if (p.dbg && (p.debug_flags & 128) && lane == 0)   // per-block completion stamps (after the strip stamps and counters)
                         p.dbg[6 * p.nstrips + 64 + (int64_t)s * nblk + q] = __builtin_amdgcn_s_memrealtime();
+                    if (p.bot_gran && q == nblk - 1) {
+                        // band-resident launch: the band's last row leaves as {tag, H} granules (the next band's halo row)
+                        u32 gl = 0;
+                        sfor<0, SY_U>([&](auto K) { if (K.value + 1 == nb) gl = gv[K.value + 1]; });
+                        const int hl = (int)gl - (cz + ngap * rows);
+                        if (cell_ok)
+                            __hip_atomic_store((gu64*)(p.bot_gran + j), ((u64)p.bot_tag << 32) | (u64)(u32)hl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (p.bot_done) {
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (lane == 0) __hip_atomic_store((gu32*)(p.bot_done + s), p.bot_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
                     if constexpr (NC > 4) {
                         // a slot shared by two consumers is published in block order: wait for the block before mine
                         if (partner >= 0) {
@@ -940,16 +1006,13 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 }
                 // arg-max: the lowest row of block `bestblk` holding bestv in my column (re-read what this wave stored)
                 if (cell_ok && !(p.debug_flags & 1) && bestv > 0) {
-                    int bestrow = bestblk * SY_U + 1;
-                    if (p.store_hp) {
+                    if (reread) {
+                        bestrow = bestblk * SY_U + 1;
                         __builtin_amdgcn_s_waitcnt(0);  // my own stores have reached L2
                         for (int k = SY_U - 1; k >= 0; --k) {
                             const int r = bestblk * SY_U + 1 + k;
                             if (r <= rows && (int)__builtin_nontemporal_load(&H[(int64_t)r * M + j]) == bestv) bestrow = r;
                         }
-                    } else {
-                        // score-only: recompute the 16 rows of that block from the ring?  It is long gone: report the
-                        // block's first row (max_score is exact; max_pos is exact only with store_hp)
                     }
                     const u64 idx = (u64)bestrow * (u64)M + (u64)j;
                     atomicMax(p.result_key, ((u64)(u32)bestv << 40) | (SW_KEY_IDX_MASK - idx));
@@ -964,7 +1027,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
             __builtin_amdgcn_s_setprio(2);  // short, latency-critical loops: ahead of the consumers on their SIMD
             const bool do_export = (slast + 1 < p.nstrips);
             const int phi0 = phi_of(s0, phib), phil = phi_of(slast, phib);
-            const u32 halo_row0 = (u32)((p.top ? p.top[(int64_t)s0 * SY_W] : 0) + ngap * s0 * SY_W);
+            const u32 halo_row0 = (u32)(top_at(0, 0, (int64_t)s0 * SY_W) + ngap * s0 * SY_W);
             // import starts at row 0 (the diagonal neighbour of row 1); with the fast producers at the row of
             // strip s0's local step 1: the cells above the matrix hold the H == 0 floor there
             int imp = (phib >= 0) ? 1 - phi0 : 0, exp = 1;
@@ -983,6 +1046,10 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
             while ((importer && imp <= rows) || (exporter && do_export && exp <= rows)) {
                 bool progressed = false;
                 if (importer && imp <= rows) {
+                    // with several importers: never work behind the published front (a wave that fell a ring length behind
+                    // would overwrite slots the leader has refilled)
+                    const int front = lds_load(&lds.halo_ready);
+                    if (front > 1) imp = max(imp, front - phi0);
                     // halo[] holds RH steps and strip s0's producer has consumed every step <= its progress:
                     // rows < lim may be written.  One 64-row window per round trip to HBM/L2 while the importer
                     // rides the left neighbour's front (latency matters); four windows while it is catching up.
@@ -1026,13 +1093,15 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                                 oks[b4] = ok;
                             }
                         }
+                        const int front2 = lds_load(&lds.halo_ready);   // rows below it are published (and may be consumed): leave them alone
 #pragma unroll
                         for (int b4 = 0; b4 < nbat; ++b4) {
                             const int r = imp + b4 * 64 + lane;
                             const u64 okm = __ballot(oks[b4]);
                             const int npre = (okm == ~0ull) ? 64 : __builtin_ctzll(~okm);  // leading run of valid rows
                             if (base == imp + b4 * 64 && npre > 0) {                       // contiguous with what is imported
-                                if (lane < npre) __hip_atomic_store(&lds.halo[(r + phi0 - 1) & (SY_RH - 1)], vals[b4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (lane < npre && (front2 <= 1 || r + phi0 >= front2))
+                                    __hip_atomic_store(&lds.halo[(r + phi0 - 1) & (SY_RH - 1)], vals[b4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 base += npre;
                             }
                         }

@@ -65,6 +65,9 @@ class GpuTiles:
         self.eng.synchronize()
         self.left, self.right = self.right, self.left
         r = self.res.cpu().tolist()
+        if r[2] < 0:
+            from . import SwError
+            raise SwError(-62, "in-kernel hand-off wait timed out")
         bottom = self.H[self.band_rows, j0:j1 + 1].to(self.t.int32)
         # tile-local arg-max -> band-local (row, col)
         row, col = divmod(r[0], self.cols + 1) if r[1] > 0 else (0, 0)

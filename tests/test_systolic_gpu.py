@@ -1,0 +1,145 @@
+"""GPU: systolic-engine-only parity tests (tuning options, compact P, BASELINE config 3 at full size)."""
+import numpy as np
+import pytest
+
+from test_fill_gpu import check_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def engine_kind(engine):
+    engine.set_option("engine", 0)
+    yield 0
+
+
+TUNINGS = [
+    {"strips_per_group": 2, "consumers": 2}, {"strips_per_group": 2, "consumers": 3}, {"strips_per_group": 2, "consumers": 4}, {"strips_per_group": 1, "consumers": 2},
+    {"strips_per_group": 1, "consumers": 3}, {"strips_per_group": 1, "consumers": 4}, {"strips_per_group": 1, "consumers": 6},
+    {"strips_per_group": 1, "consumers": 8}, {"store_policy": 1}, {"store_policy": 2}, {"xcd_order": 1},
+    {"xcd_order": 1, "max_blocks": 20}, {"pace_ps": 40000}, {"importers": 2}, {"importers": 2, "strips_per_group": 1, "consumers": 4}, {"store_policy": 2, "xcd_order": 1, "strips_per_group": 1, "consumers": 8},
+]
+
+
+@pytest.mark.parametrize("opts", TUNINGS, ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+@pytest.mark.parametrize("h64", [False, True], ids=["h32", "h64"])
+def test_tuning_options_do_not_change_results(engine, oracle, engine_kind, opts, h64):
+    """Workgroup shape, store cache policy, XCD order and pacing only move time: H, P and the arg-max stay bit-exact."""
+    import torch
+    a, b = oracle.generate(4200, 1300, 21)   # 67 strips: enough groups for the XCD-aware order and a second pass
+    defaults = {k: engine.get_option(k) for k in opts}
+    for k, v in opts.items():
+        engine.set_option(k, v)
+    try:
+        check_against_oracle(engine, oracle, a, b, h_dtype=torch.int64 if h64 else None)
+    finally:
+        for k, v in defaults.items():
+            engine.set_option(k, v)
+
+
+@pytest.mark.parametrize("h64", [False, True], ids=["h32", "h64"])
+@pytest.mark.parametrize("cols,rows", [(1000, 700), (63, 16), (4200, 1300), (130, 1029)])
+def test_compact_p_int8(engine, oracle, swamd, engine_kind, cols, rows, h64):
+    """sw_fill_device_ex with one byte per predecessor code: same H, arg-max, codes, traceback and checksums."""
+    import torch
+    a, b = oracle.generate(cols, rows, 29)
+    H, P, mp = oracle.fill(a, b)
+    for policy in (1, 2):
+        engine.set_option("store_policy", policy)
+        try:
+            out = engine.fill(a, b, h_dtype=torch.int64 if h64 else None, p_dtype=torch.int8)
+        finally:
+            engine.set_option("store_policy", 0)
+        assert out.P.dtype == torch.int8
+        assert np.array_equal(out.H.cpu().numpy().astype(np.int64), H.astype(np.int64))
+        assert np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
+        assert out.result()["max_pos"] == mp
+        assert np.array_equal(engine.row_checksums(out.P), oracle.row_checksums(P))   # int8 P checksums like its int32 widening
+    P8 = out.P.cpu().numpy().copy()
+    path = engine.traceback(out, mp)
+    P1 = P.copy()
+    opath = oracle.backtrack(P1, mp)
+    assert np.array_equal(path, opath) and np.array_equal(out.P.cpu().numpy().astype(np.int32), P1)
+    hpath = swamd.traceback_host(P8, mp)
+    assert np.array_equal(hpath, opath) and np.array_equal(P8.astype(np.int32), P1)
+
+
+def test_config3_65536_int64_streaming_checksums(engine, oracle, swamd, engine_kind):
+    """BASELINE config 3 (65536 x 65536, int64 H + int32 P, resident in HBM): per-row checksums, arg-max, bottom row
+    against the streaming oracle; every int64 H must be the sign extension of its int32 value.  ~20 s."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < (60 << 30):
+        pytest.skip(f"needs 60 GB of free HBM, {free >> 30} GB free")
+    n = 65536
+    a, b = swamd.generate(n, n, 1)
+    d_a, _ = engine.to_device(a)
+    d_b, _ = engine.to_device(b)
+    out = engine.alloc(n, n, torch.int64)
+    engine.fill_into(out, d_a, d_b)
+    engine.synchronize()
+    r = out.result()
+    csH, csP = engine.row_checksums(out.H), engine.row_checksums(out.P)
+    bottom = out.H[-1].cpu().numpy()
+    st = oracle.fill_streaming(a, b)
+    assert r["max_pos"] == st["max_pos"] and r["max_score"] == st["max_score"]
+    assert np.array_equal(csH, st["csH"]) and np.array_equal(csP, st["csP"])
+    assert np.array_equal(bottom.astype(np.int32), st["bottom"]) and bottom.dtype == np.int64
+    plen = engine.traceback(out, want_path=False)
+    assert n < plen < 3 * n
+
+
+def test_strip_scan_engine_rejects_compact_p(engine, oracle, swamd):
+    import torch
+    a, b = oracle.generate(200, 100, 3)
+    engine.set_option("engine", 1)
+    try:
+        with pytest.raises(swamd.SwError):
+            engine.fill(a, b, p_dtype=torch.int8)
+    finally:
+        engine.set_option("engine", 0)
+
+
+@pytest.mark.parametrize("cols,rows", [(1000, 700), (63, 16), (4200, 1300)])
+@pytest.mark.parametrize("mode", ["p8_only", "p32_only", "h_only", "score_only"])
+def test_matrix_less_fills(engine, oracle, mode, cols, rows):
+    """sw_fill_device_ex with d_H and/or d_P NULL (P-only, H-only, score-only): what is written is
+    bit-exact, the arg-max is exact in every mode (serial_smithW.c:240-242), the P-only traceback equals backtrack()."""
+    import torch
+    a, b = oracle.generate(cols, rows, 31)
+    H, P, mp = oracle.fill(a, b)
+    want_h = mode == "h_only"
+    want_p = mode in ("p8_only", "p32_only")
+    out = engine.fill(a, b, p_dtype=torch.int8 if mode == "p8_only" else None, want_h=want_h, want_p=want_p)
+    r = out.result()
+    assert r["max_pos"] == mp and r["max_score"] == int(H.flat[mp])
+    assert (out.H is None) == (not want_h) and (out.P is None) == (not want_p)
+    if want_h:
+        assert np.array_equal(out.H.cpu().numpy(), H)
+    if want_p:
+        assert np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
+        path = engine.traceback(out, mp)
+        P1 = P.copy()
+        assert np.array_equal(path, oracle.backtrack(P1, mp)) and np.array_equal(out.P.cpu().numpy().astype(np.int32), P1)
+
+
+def test_argmax_ties_without_h(engine, oracle):
+    """Score-only arg-max on inputs full of ties: the LOWEST linear index among the maxima (serial_smithW.c:240-242)."""
+    for a, b in ((b"ACGT" * 80, b"ACGT" * 70), (b"A" * 300, b"A" * 200), (b"A" * 300, b"C" * 200), (b"ACGT" * 300, b"TGCA" * 290)):
+        H, P, mp = oracle.fill(a, b)
+        r = engine.fill(a, b, want_h=False, want_p=False).result()
+        assert r["max_pos"] == mp and r["max_score"] == int(H.flat[mp])
+
+
+def test_stalled_strip_times_out_and_context_recovers(engine, oracle, swamd):
+    """The in-kernel abort path: a strip that never runs (debug bit 3) makes every wait give up; the call reports
+    SW_ETIMEOUT instead of hanging, and the same context then fills correctly again."""
+    a, b = oracle.generate(600, 300, 17)
+    engine.set_option("debug_flags", 8)
+    try:
+        with pytest.raises(swamd.SwError) as e:
+            engine.fill(a, b).result()
+        assert e.value.code == -62
+    finally:
+        engine.set_option("debug_flags", 0)
+    check_against_oracle(engine, oracle, a, b)

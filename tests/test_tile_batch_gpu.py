@@ -73,6 +73,61 @@ def test_batch_1024_pairs_config5_shape(engine, oracle, swamd):
         assert np.array_equal(H[k].cpu().numpy(), hh) and np.array_equal(P[k].cpu().numpy(), pp) and res[k, 0] == mp
 
 
+def test_batch_at_scale_shape_small_pairs(engine, oracle):
+    """The launch shape BASELINE config 5 uses at 100 000 pairs -- two strips per workgroup, several passes of the
+    resident grid over the strip groups, more than one 4096-pair chunk -- on 5000 small pairs: EVERY pair's H, P and
+    arg-max against the oracle."""
+    rng = np.random.default_rng(11)
+    npairs, cols, rows = 5000, 130, 70
+    A = (rng.integers(0, 4, (npairs, cols)) + 65).astype(np.uint8)
+    B = (rng.integers(0, 4, (npairs, rows)) + 65).astype(np.uint8)
+    res, H, P = engine.batch(A, B, store=True)
+    assert engine.get_option("last_grid") == engine.get_option("num_cus")   # capped grid: many passes per workgroup
+    res, H, P = res.cpu().numpy(), H.cpu().numpy(), P.cpu().numpy()
+    assert (res[:, 2] == 0).all()
+    for k in range(npairs):
+        h, p, mp = oracle.fill(A[k], B[k])
+        assert np.array_equal(H[k], h) and np.array_equal(P[k], p), f"pair {k}"
+        assert res[k, 0] == mp and res[k, 1] == int(h.flat[mp]), f"pair {k} arg-max"
+    res2, _, _ = engine.batch(A, B, store=False)   # score-only: same scores, same exact arg-max
+    assert np.array_equal(res2.cpu().numpy(), res)
+
+
+def test_batch_300_pairs_of_1024_vs_oracle(engine, oracle, swamd):
+    """BASELINE config 5's pair shape (1024 x 1024, pair k seeded 1+k), 300 pairs = 5100 strips (20 passes of the grid):
+    H, P, arg-max of every pair against the oracle."""
+    npairs = 300
+    gen = [swamd.generate(1024, 1024, 1 + k) for k in range(npairs)]
+    A, B = np.stack([g[0] for g in gen]), np.stack([g[1] for g in gen])
+    res, H, P = engine.batch(A, B, store=True)
+    res = res.cpu().numpy()
+    for k in range(npairs):
+        h, p, mp = oracle.fill(A[k], B[k])
+        assert np.array_equal(H[k].cpu().numpy(), h) and np.array_equal(P[k].cpu().numpy(), p), f"pair {k}"
+        assert res[k, 0] == mp and res[k, 1] == int(h.flat[mp]), f"pair {k} arg-max"
+    res2, _, _ = engine.batch(A, B, store=False)
+    assert np.array_equal(res2.cpu().numpy(), res)
+
+
+def test_batch_compact_p_and_traceback(engine, oracle):
+    """BASELINE config 5's deliverable per pair -- score, maxPos, path -- with int8 P and no H (5x less memory):
+    sw_batch_device_ex + sw_batch_traceback_device against the oracle's fill + backtrack for every pair."""
+    import torch
+    rng = np.random.default_rng(5)
+    npairs, cols, rows = 700, 200, 150
+    A = (rng.integers(0, 4, (npairs, cols)) + 65).astype(np.uint8)
+    B = (rng.integers(0, 4, (npairs, rows)) + 65).astype(np.uint8)
+    A[3], B[3] = 65, 67          # a pair without any match: H == 0, maxPos 0, empty path
+    res, H, P, paths = engine.batch(A, B, store=True, p_dtype=torch.int8, store_h=False, traceback=True, want_paths=True)
+    assert H is None and P.dtype == torch.int8
+    res, P, paths = res.cpu().numpy(), P.cpu().numpy(), paths.cpu().numpy()
+    for k in range(npairs):
+        h, p, mp = oracle.fill(A[k], B[k])
+        opath = oracle.backtrack(p, mp)   # p is negated along the path now
+        assert res[k, 0] == mp and res[k, 1] == int(h.flat[mp]) and res[k, 2] == len(opath), f"pair {k}"
+        assert np.array_equal(paths[k, :len(opath)], opath) and np.array_equal(P[k].astype(np.int32), p), f"pair {k} path"
+
+
 def test_band_pipeline_single_gpu(engine, oracle):
     """BandPipeline with the GPU tile engine, world_size 1 (several chunks): exercises GpuTiles end to end."""
     import torch.distributed as dist
