@@ -191,7 +191,7 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *   "engine"            0 systolic (default), 1 strip_scan
  *   "strips_per_group"  systolic: strips (producer waves) per workgroup, 1 or 2 (0: 1 for a single pair with up to
  *                       4.5 strips per CU or a batch that fits the CUs at once, else 2)
- *   "consumers"         systolic: consumer waves per strip: 2, 3, 4; also 6, 8 with one strip per group (0: 8 / 4)
+ *   "consumers"         systolic: consumer waves per strip: 2, 3, 4; also 6, 7 with one strip per group (0: 6 / 4; 8 is taken as 7)
  *   "store_policy"      systolic H/P stores: 0 by problem size, 1 write-back, 2 streaming (nt)
  *   "importers"         systolic, one strip per workgroup: waves polling the left neighbour's edge column (default 2;
  *                       at most what 12 waves per workgroup leave)

@@ -41,8 +41,12 @@ struct sw_ctx {
     size_t edge_cap = 0;                // granules
     unsigned long long* d_key = nullptr; // [0] = arg-max key, [1] low word = abort flag
     unsigned long long* d_keys = nullptr; size_t keys_cap = 0;  // batch: one key per pair
-    unsigned char* d_cb = nullptr;      // systolic engine: zero-padded copy of b (sw_pad_b)
+    unsigned char* d_cb = nullptr;      // systolic engine: padded copies of b (bytes, 16-bit, letter codes; sw_pad_b)
     size_t cb_cap = 0;
+    unsigned int* d_edge4 = nullptr;    // perm producer: lane-63 columns as self-tagged 4-byte values
+    size_t edge4_cap = 0;               // elements
+    unsigned epoch8 = 0;                // 8-bit launch tag of those values
+    unsigned char* d_alpha = nullptr;   // [0..31] presence map of byte values, [64..323] letter code table + letter count
     int64_t opt_debug = 0;
     int64_t opt_store_policy = 0;       // systolic H/P stores: 0 auto (by size), 1 write-back, 2 streaming (nt)
     int64_t opt_xcd_order = 0;          // systolic: 1 = neighbouring strip groups on one XCD
@@ -73,6 +77,8 @@ int sw_create(int device, sw_ctx** out) {
     c->num_cus = prop.multiProcessorCount;
     HIP_TRY(hipMalloc((void**)&c->d_key, 64));
     HIP_TRY(hipMemset(c->d_key, 0, 64));
+    HIP_TRY(hipMalloc((void**)&c->d_alpha, 512));
+    HIP_TRY(hipMemset(c->d_alpha, 0, 512));
     *out = c;
     return SW_OK;
 }
@@ -83,6 +89,8 @@ void sw_destroy(sw_ctx* c) {
     if (c->d_edge) (void)hipFree(c->d_edge);
     if (c->d_key) (void)hipFree(c->d_key);
     if (c->d_cb) (void)hipFree(c->d_cb);
+    if (c->d_edge4) (void)hipFree(c->d_edge4);
+    if (c->d_alpha) (void)hipFree(c->d_alpha);
     if (c->d_keys) (void)hipFree(c->d_keys);
     delete c;
 }
@@ -169,6 +177,7 @@ struct FillJob {
     unsigned int top_tag = 0, bot_tag = 0;
     int reserve_cus = 0;          // CUs left free for other kernels (halo transfers)
     bool concurrent = false;      // do not order this launch behind fills on other streams (the caller partitions the CUs)
+    int64_t total_rows = 0;       // band: rows of the whole matrix (bounds the scores a halo can carry)
 };
 
 // called with g_dev[device].mu held: make `stream` wait for the fills enqueued on other streams of this device
@@ -244,21 +253,60 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         // for 20000 pairs, 203 vs 143 for 64).
         int NS = (int)c->opt_strips_per_group, NC = (int)c->opt_consumers;
         if (NS == 0) NS = (j.npairs == 1 ? (double)S <= 4.5 * c->num_cus : (double)S * (double)j.npairs <= (double)c->num_cus) ? 1 : 2;
-        if (NC == 0) NC = (NS == 1) ? 8 : 4;
+        if (NC == 0) NC = (NS == 1) ? 6 : 4;   // NS == 1: 6 consumers + exporter + 2 importers on the three SIMDs the producer leaves
+        if (NS == 1 && NC > 7) NC = 7;         // nine waves off the producer's SIMD: at most 7 consumers + exporter + importer
         // padded copies of b per problem: [front | b | tail]; front covers the fast producers' phi (< strips) + 63 lanes
-        const int64_t bfront = ((S + 64 + 127) / 128) * 128;
+        // (+ one 16-step block: the perm producer's first score window ends at step 0)
+        const int64_t bfront = ((S + 64 + 32 + 127) / 128) * 128;
         const int64_t per = ((rows + bfront + 512 + 15) / 16) * 16;
         const size_t ncb = (size_t)per * (size_t)j.npairs;
         if (ncb > c->cb_cap) {
             HIP_TRY(hipStreamSynchronize(stream));
             if (c->d_cb) HIP_TRY(hipFree(c->d_cb));
             c->d_cb = nullptr; c->cb_cap = 0;
-            if (hipMalloc((void**)&c->d_cb, ncb * 3 + 16) != hipSuccess) { set_err("workspace allocation failed"); return SW_ENOMEM; }
+            if (hipMalloc((void**)&c->d_cb, ncb * 4 + 64) != hipSuccess) { set_err("workspace allocation failed"); return SW_ENOMEM; }
             c->cb_cap = ncb;
         }
-        unsigned short* d_cb16 = (unsigned short*)(c->d_cb + ((c->cb_cap + 15) / 16) * 16);
+        const size_t cb16 = ((c->cb_cap + 15) / 16) * 16;
+        unsigned short* d_cb16 = (unsigned short*)(c->d_cb + cb16);
+        unsigned char* d_cbc = c->d_cb + cb16 + ((2 * c->cb_cap + 15) / 16) * 16;
+        // perm producer (alphabets of up to 7 letters): eligible when the scores fit a signed byte and every G value,
+        // with the 2^16 bias, stays below 2^24 (the top byte carries the launch tag)
+        const int64_t lo = std::min(cols, rows);
+        const int64_t gmax = (int64_t)sc->match * std::max<int64_t>(lo, std::min(cols, j.total_rows)) + (int64_t)(-sc->gap) * (rows + cols + 2);
+        const bool halo_unbounded = (j.d_top || j.d_left) && j.total_rows == 0;   // a tile whose halo magnitudes are unknown here
+        const bool perm_ok = !halo_unbounded && p.mm <= 127 && p.mm >= -127 && p.xm <= 127 && p.xm >= -127 && gmax + 0x10000 + 1024 < (1ll << 24) &&
+                             !(c->opt_debug & 16);
+        if (perm_ok) {
+            const int64_t e4stride = ((rows + S + 96 + 3) / 4) * 4;
+            const size_t need4 = (size_t)S * (size_t)e4stride * (size_t)j.npairs;
+            if (need4 > c->edge4_cap) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (c->d_edge4) HIP_TRY(hipFree(c->d_edge4));
+                c->d_edge4 = nullptr; c->edge4_cap = 0;
+                if (hipMalloc((void**)&c->d_edge4, need4 * 4) != hipSuccess) { set_err("workspace allocation of %zu bytes failed", need4 * 4); return SW_ENOMEM; }
+                c->edge4_cap = need4;
+                HIP_TRY(hipMemsetAsync(c->d_edge4, 0, need4 * 4, stream));
+                c->epoch8 = 0;
+            }
+            if (++c->epoch8 >= 256) {   // 8-bit tag wrapped: wipe stale values
+                HIP_TRY(hipMemsetAsync(c->d_edge4, 0, c->edge4_cap * 4, stream));
+                c->epoch8 = 1;
+            }
+            p.edge4 = c->d_edge4; p.e4stride = e4stride; p.edge4_pstride = (int64_t)S * e4stride;
+            p.gbias = (c->epoch8 << 24) | 0x10000u;
+        }
+        HIP_TRY(hipMemsetAsync(c->d_alpha, 0, 32, stream));
+        {
+            const int64_t total = (cols + rows) * j.npairs;
+            const unsigned nblk = (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 4095) / 4096, 1024));
+            hipLaunchKernelGGL(swk::sw_alpha_scan, dim3(nblk), dim3(256), 0, stream, ua, cols, j.a_pstride, ub, rows, j.b_pstride, j.npairs,
+                               (unsigned int*)c->d_alpha);
+        }
         hipLaunchKernelGGL(swk::sw_pad_b, dim3((unsigned)((per + 255) / 256), (unsigned)j.npairs), dim3(256), 0, stream, ub, rows, bfront,
-                           j.b_pstride, c->d_cb, d_cb16, per);
+                           j.b_pstride, c->d_cb, d_cb16, d_cbc, (const unsigned int*)c->d_alpha, c->d_alpha + 64, per);
+        p.bcode = d_cbc;
+        p.atab = c->d_alpha + 64;
         const bool fast = (j.d_top == nullptr) && (j.d_top_gran == nullptr) && (sc->mismatch <= 0) && !(c->opt_debug & 4);
         p.phi_base = fast ? (int)S - 1 : -1;
         p.bfront = (int)bfront;
@@ -267,9 +315,15 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         const int64_t ngroups = ((S + NS - 1) / NS) * j.npairs;
         const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : std::max<int64_t>(8, (int64_t)c->num_cus - j.reserve_cus);
         int grid = (int)std::max<int64_t>(1, std::min<int64_t>(ngroups, maxb));
-        const int base_waves = NS * (1 + NC) + 2;
-        const int extra_imp = (NS == 1) ? (int)std::max<int64_t>(0, std::min<int64_t>(c->opt_importers - 1, 12 - base_waves)) : 0;
-        const int threads = 64 * (base_waves + extra_imp);
+        int threads;
+        if (NS == 1) {
+            // wave 0 (the producer) owns SIMD 0: waves 4, 8, 12 idle; consumers, the exporter and the importers are the
+            // K waves off SIMD 0 (wave id of ordinal k: k + 1 + k/3)
+            const int K = std::min<int>(9, NC + 1 + (int)std::max<int64_t>(1, c->opt_importers));   // 12 waves: 3 per SIMD
+            threads = 64 * (K + (K - 1) / 3 + 1);
+        } else {
+            threads = 64 * (NS * (1 + NC) + 2);
+        }
         const unsigned char* cbp = c->d_cb;
         bool launched = false;
         // every workgroup of the grid must be resident (they wait for each other): never launch more than the occupancy
@@ -288,7 +342,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         else                                                                                                                      \
             hipLaunchKernelGGL((swk::sw_systolic<int64_t, ns, nc>), dim3(grid), dim3(threads), 0, stream, ua, ub, cbp, p);       \
     }
-        SW_LAUNCH(2, 2) SW_LAUNCH(2, 3) SW_LAUNCH(2, 4) SW_LAUNCH(1, 2) SW_LAUNCH(1, 3) SW_LAUNCH(1, 4) SW_LAUNCH(1, 6) SW_LAUNCH(1, 8)
+        SW_LAUNCH(2, 2) SW_LAUNCH(2, 3) SW_LAUNCH(2, 4) SW_LAUNCH(1, 2) SW_LAUNCH(1, 3) SW_LAUNCH(1, 4) SW_LAUNCH(1, 6) SW_LAUNCH(1, 7)
 #undef SW_LAUNCH
         if (!launched) { set_err("unsupported strips_per_group/consumers combination %d/%d", NS, NC); return SW_EINVAL; }
     } else {
@@ -385,7 +439,7 @@ int sw_fill_band_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_
     if (c && c->opt_engine != 0) { set_err("sw_fill_band_device needs the systolic engine"); return SW_EINVAL; }
     FillJob j = make_job(d_a, cols, d_b, rows, d_H, h_elem_bytes, d_P, p_elem_bytes, cols + 1, nullptr, nullptr, nullptr);
     j.d_top_gran = (const unsigned long long*)d_top_gran; j.d_bot_gran = (unsigned long long*)d_bot_gran; j.d_bot_done = d_bot_done;
-    j.top_tag = top_tag; j.bot_tag = bot_tag; j.reserve_cus = reserve_cus; j.concurrent = concurrent != 0;
+    j.top_tag = top_tag; j.bot_tag = bot_tag; j.reserve_cus = reserve_cus; j.concurrent = concurrent != 0; j.total_rows = total_rows;
     return fill_one(c, scores, j, cols, total_rows, d_result, stream_, "sw_fill_band_device");
 }
 

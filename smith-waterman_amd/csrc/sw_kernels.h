@@ -43,13 +43,25 @@ struct FillParams {
     unsigned int* bot_done;              // optional [nstrips]: set to bot_tag (system scope, after a release) once the strip's bottom granules are written
     unsigned int top_tag, bot_tag;
     unsigned int top_wait_ticks;         // patience of the top-halo poll in 100 MHz ticks / 2^10
+    // "perm" producer (systolic; alphabets of at most 7 letters, scores that fit a signed byte): the substitution
+    // scores of 16 steps come from 4 v_perm_b32 over a per-lane profile, every G value carries `gbias` (8-bit launch
+    // tag << 24 | 2^16), and lane 63 stores its own results as self-validating 4-byte values
+    const unsigned char* bcode;          // padded copy of b as letter codes 0..6 (7 = outside the sequence), layout as bpad
+    const unsigned char* atab;           // [256] letter code of every byte value; [256..259] = number of letters (uint32)
+    unsigned int* edge4;                 // [nstrips][e4stride] lane-63 values indexed by the producer's local step - 1
+    int64_t e4stride, edge4_pstride;
+    unsigned int gbias;                  // 0 = perm path not eligible on the host side (score range)
 };
+constexpr int SW_PERM_PAD = -100;        // score of any cell outside the sequences (perm producer)
 
 template <typename HT, int B>
 __global__ void sw_strip_scan(const unsigned char* a, const unsigned char* b, FillParams p);
 template <typename HT, int NS, int NC>
 __global__ void sw_systolic(const unsigned char* a, const unsigned char* b, const unsigned char* bpad, FillParams p);
-__global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, int64_t b_pstride, unsigned char* bpad, unsigned short* bpad16, int64_t per);
+__global__ void sw_alpha_scan(const unsigned char* a, int64_t cols, int64_t a_pstride, const unsigned char* b, int64_t rows, int64_t b_pstride,
+                              int64_t npairs, unsigned int* present);
+__global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, int64_t b_pstride, unsigned char* bpad, unsigned short* bpad16,
+                         unsigned char* bcode, const unsigned int* present, unsigned char* atab, int64_t per);
 __global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res, int n);
 template <typename PT>
 __global__ void sw_traceback(PT* P, int64_t M, int64_t maxPos, int64_t* path, int64_t cap, sw_result* res);

@@ -397,6 +397,249 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
 
 
 // =================================================================================================
+// "Perm" producer (round 2): FOUR VALU instructions per anti-diagonal step instead of six.
+//     A: P      = max3(t[u-2], g[u-1], Z)      v_max3_i32        t = g + s' of the cell diagonally below-right
+//     B: Z     += ngap                          v_add_u32
+//     C: t[u-1] = g[u-1] + sext(S.byte)         v_add_u32_sdwa    S: this block's 16 score bytes
+//     D: g[u]   = max(P[l-1], g[u-1][l])        v_max_i32_dpp wave_shr:1   (lane 0 is not written: it keeps the halo value
+//                                                                   a broadcast ds_read_b128 put there 8 steps earlier)
+// i.e. g[l] = max(t2[l-1], g1[l-1], g1[l], Z): the shifted maximum is formed BEFORE the shift, so one DPP op does both
+// lane moves.  The scores are not computed per step: letters are coded 0..6 (7 = outside the sequences) by sw_pad_b,
+// every lane holds its column's profile (8 score bytes, one per code) in two VGPRs, and ONE v_perm_b32 with four code
+// bytes of b as the selector yields four steps of scores -- 4 v_perm + 1 code load per 16 steps.  Cells outside the
+// sequences score SW_PERM_PAD: above the matrix every lane then simply keeps its row-0 value (G is non-decreasing along
+// row 0), so a halo row needs no injection and the mismatch score may be positive.
+// All G values carry p.gbias (launch tag << 24 | 2^16; G-space is translation invariant), which makes every exported
+// value self-validating: lane 63 stores its own four results per group with one buffer_store_dwordx4 (the other lanes'
+// offsets are out of range) -- no exporter wave, no progress poll, no ring read on the way out.
+// Checked step by step against a host restatement and timed in tools/ubench_perm.hip (28.5 clk per step alone).
+//
+// literal registers (temporaries of this one statement):
+//   v[100:115] g of the 16 steps of a block (lane 0: halo)    v[116:119] t    v120 P    v121 Z
+//   v[122:125] / v[60:63] score bytes of even / odd blocks     v[64:79] four code buffers (loaded 3 blocks ahead)
+//   v[80:83], v84 back-pressure counters   v86 left progress   v87, v92 scratch   v88..v91 LDS addresses of the counters
+//   v96 code offset   v97 export offset (lane 63: 0, others out of range)   v98/v99 halo read base of this/next chunk
+//   v126 ring write address
+//   s84 have_halo  s85..s87 scratch  s88 u0  s89 spin  s90/s91 chunk byte offset in my ring / the halo ring
+//   s[92:93] code base  s94/s95 slow-path poll counts  s[76:79] export buffer  s75 export chunk offset
+// =================================================================================================
+#define PP_STEP(GK, GP, TP2, TP1, SREG, BYTE)                                                     \
+    "v_max3_i32 v120, " TP2 ", " GP ", v121\n\t"                                                  \
+    "v_add_u32 v121, v121, %[ngap]\n\t"                                                           \
+    "v_add_u32_sdwa " TP1 ", " GP ", sext(" SREG ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BYTE "\n\t" \
+    "v_max_i32_dpp " GK ", v120, " GP " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define PP_G0(SP3, S0)                                                                            \
+    PP_STEP("v100", "v115", "v118", "v119", SP3, "BYTE_3") PP_STEP("v101", "v100", "v119", "v116", S0, "BYTE_0")   \
+    PP_STEP("v102", "v101", "v116", "v117", S0, "BYTE_1") PP_STEP("v103", "v102", "v117", "v118", S0, "BYTE_2")
+#define PP_G1(S0, S1)                                                                             \
+    PP_STEP("v104", "v103", "v118", "v119", S0, "BYTE_3") PP_STEP("v105", "v104", "v119", "v116", S1, "BYTE_0")   \
+    PP_STEP("v106", "v105", "v116", "v117", S1, "BYTE_1") PP_STEP("v107", "v106", "v117", "v118", S1, "BYTE_2")
+#define PP_G2(S1, S2)                                                                             \
+    PP_STEP("v108", "v107", "v118", "v119", S1, "BYTE_3") PP_STEP("v109", "v108", "v119", "v116", S2, "BYTE_0")   \
+    PP_STEP("v110", "v109", "v116", "v117", S2, "BYTE_1") PP_STEP("v111", "v110", "v117", "v118", S2, "BYTE_2")
+#define PP_G3(S2, S3)                                                                             \
+    PP_STEP("v112", "v111", "v118", "v119", S2, "BYTE_3") PP_STEP("v113", "v112", "v119", "v116", S3, "BYTE_0")   \
+    PP_STEP("v114", "v113", "v116", "v117", S3, "BYTE_1") PP_STEP("v115", "v114", "v117", "v118", S3, "BYTE_2")
+// One 16-step block.  KB: first step's index in the chunk.  SP3: score dword holding the step before the block;
+// S0..S3 / C0..C3: this block's score and code dwords; NB, PF: code buffer that receives the block three ahead and its
+// byte offset; HN0, HN1: operands of the next block's first two halo groups; L0/L1/LE: lgkmcnt of the waits for halo
+// group 0 / group 1 / the left counter (they differ where back-pressure fetches sit in the LDS queue); BPF: those fetches.
+// LDS order: [G0] W0 R2 [G1] W1 R3 [G2] W2 Rc R0' [G3] W3 R1' (BPF) | evaluate Rc | Wp
+#define PP_BLOCK(KB, SP3, S0, S1, S2, S3, C0, C1, C2, C3, NB, PF, O0, O1, O2, O3, H2, H3, HN0, HN1, L0, L1, LE, BPF)  \
+    "s_cmp_eq_u32 s84, 0\n\t"                                                                \
+    "s_cbranch_scc1 Lslow" #KB "_%=\n"                                                       \
+    "Lgo" #KB "_%=:\n\t"                                                                     \
+    "s_waitcnt vmcnt(14)\n\t"                                                                \
+    "global_load_dwordx4 " NB ", v96, s[92:93] offset:" PF "\n\t"                            \
+    "v_perm_b32 " S0 ", %[phi], %[plo], " C0 "\n\t"                                          \
+    "v_perm_b32 " S1 ", %[phi], %[plo], " C1 "\n\t"                                          \
+    "v_perm_b32 " S2 ", %[phi], %[plo], " C2 "\n\t"                                          \
+    "v_perm_b32 " S3 ", %[phi], %[plo], " C3 "\n\t"                                          \
+    "s_waitcnt lgkmcnt(" L0 ")\n\t"                                                          \
+    PP_G0(SP3, S0)                                                                           \
+    "ds_write_b128 v126, v[100:103] offset:" O0 "\n\t"                                       \
+    "buffer_store_dwordx4 v[100:103], v97, s[76:79], s75 offen offset:" O0 " sc1\n\t"        \
+    "ds_read_b128 v[108:111], v98 offset:" H2 "\n\t"                                         \
+    "s_waitcnt lgkmcnt(" L1 ")\n\t"                                                          \
+    PP_G1(S0, S1)                                                                            \
+    "ds_write_b128 v126, v[104:107] offset:" O1 "\n\t"                                       \
+    "buffer_store_dwordx4 v[104:107], v97, s[76:79], s75 offen offset:" O1 " sc1\n\t"        \
+    "ds_read_b128 v[112:115], v98 offset:" H3 "\n\t"                                         \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                               \
+    PP_G2(S1, S2)                                                                            \
+    "ds_write_b128 v126, v[108:111] offset:" O2 "\n\t"                                       \
+    "buffer_store_dwordx4 v[108:111], v97, s[76:79], s75 offen offset:" O2 " sc1\n\t"        \
+    /* the left neighbour's progress, THEN (in LDS order behind it) the next block's first two halo groups */  \
+    "ds_read_b32 v86, v88\n\t"                                                               \
+    "ds_read_b128 v[100:103], " HN0 "\n\t"                                                   \
+    "s_waitcnt lgkmcnt(3)\n\t"                                                               \
+    PP_G3(S2, S3)                                                                            \
+    "ds_write_b128 v126, v[112:115] offset:" O3 "\n\t"                                       \
+    "buffer_store_dwordx4 v[112:115], v97, s[76:79], s75 offen offset:" O3 " sc1\n\t"        \
+    "ds_read_b128 v[104:107], " HN1 "\n\t"                                                   \
+    BPF                                                                                      \
+    "s_waitcnt lgkmcnt(" LE ")\n\t"                                                          \
+    "v_readfirstlane_b32 s85, v86\n\t"                                                       \
+    "s_add_i32 s86, s88, %[k1]\n\t"                                                          \
+    "s_min_i32 s86, s86, %[k2]\n\t"                                                          \
+    "s_cmp_ge_i32 s85, s86\n\t"                                                              \
+    "s_cselect_b32 s84, 1, 0\n\t"                                                            \
+    "s_add_i32 s87, s88, 15\n\t"                                                             \
+    "v_mov_b32 v87, s87\n\t"                                                                 \
+    "ds_write_b32 v91, v87\n\t"                                                              \
+    "s_add_i32 s88, s88, 16\n\t"                                                             \
+    "s_cmp_gt_i32 s88, %[ut]\n\t"                                                            \
+    "s_cbranch_scc1 Lexit_%=\n\t"
+#define PP_BPFETCH "ds_read_b128 v[80:83], v89\n\tds_read_b32 v84, v90\n\t"
+#define PP_BPCHECK(T)                                                                         \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                               \
+    "v_min_i32 v92, v80, v81\n\t"                                                            \
+    "v_min3_i32 v92, v92, v82, v83\n\t"                                                      \
+    "s_mov_b32 s89, 0\n\t"                                                                   \
+    "v_readfirstlane_b32 s86, v84\n\t"                                                       \
+    "v_readfirstlane_b32 s85, v92\n"                                                         \
+    "Lbpe" T "_%=:\n\t"                                                                      \
+    "s_lshl_b32 s85, s85, 4\n\t"                                                             \
+    "s_add_i32 s85, s85, 16\n\t"                                                             \
+    "s_add_i32 s87, s88, %[kc]\n\t"                                                          \
+    "s_cmp_ge_i32 s85, s87\n\t"                                                              \
+    "s_cbranch_scc0 Lbpw" T "_%=\n\t"                                                        \
+    "s_add_i32 s87, s88, %[kr]\n\t"                                                          \
+    "s_cmp_ge_i32 s86, s87\n\t"                                                              \
+    "s_cbranch_scc1 Lbpok" T "_%=\n"                                                         \
+    "Lbpw" T "_%=:\n\t"                                                                      \
+    "s_sleep 1\n\t"                                                                          \
+    "s_add_i32 s89, s89, 1\n\t"                                                              \
+    "s_add_i32 s94, s94, 1\n\t"                                                              \
+    "s_cmp_lt_u32 s89, 0x1000000\n\t"                                                        \
+    "s_cbranch_scc0 Lbpfail_%=\n\t"                                                          \
+    "ds_read_b128 v[80:83], v89\n\t"                                                         \
+    "ds_read_b32 v84, v90\n\t"                                                               \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+    "v_min_i32 v92, v80, v81\n\t"                                                            \
+    "v_min3_i32 v92, v92, v82, v83\n\t"                                                      \
+    "s_nop 0\n\t"                                                                            \
+    "v_readfirstlane_b32 s85, v92\n\t"                                                       \
+    "v_readfirstlane_b32 s86, v84\n\t"                                                       \
+    "s_branch Lbpe" T "_%=\n"                                                                \
+    "Lbpok" T "_%=:\n\t"
+// out-of-line: wait until the left neighbour has produced this block's halo, then fetch its first two groups
+#define PP_SLOW(KB, R0, R1)                                                                   \
+    "Lslow" #KB "_%=:\n\t"                                                                   \
+    "s_mov_b32 s89, 0\n"                                                                     \
+    "Lpoll" #KB "_%=:\n\t"                                                                   \
+    "ds_read_b32 v86, v88\n\t"                                                               \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+    "v_readfirstlane_b32 s85, v86\n\t"                                                       \
+    "s_add_i32 s86, s88, %[k1]\n\t"                                                          \
+    "s_add_i32 s86, s86, -16\n\t"                                                            \
+    "s_min_i32 s86, s86, %[k2]\n\t"                                                          \
+    "s_cmp_ge_i32 s85, s86\n\t"                                                              \
+    "s_cbranch_scc1 Lrd" #KB "_%=\n\t"                                                       \
+    "s_sleep 1\n\t"                                                                          \
+    "s_add_i32 s89, s89, 1\n\t"                                                              \
+    "s_add_i32 s95, s95, 1\n\t"                                                              \
+    "s_cmp_lt_u32 s89, 0x1000000\n\t"                                                        \
+    "s_cbranch_scc1 Lpoll" #KB "_%=\n\t"                                                     \
+    "s_mov_b32 %[status], 1\n\t"                                                             \
+    "s_branch Lexit_%=\n"                                                                    \
+    "Lrd" #KB "_%=:\n\t"                                                                     \
+    "ds_read_b128 v[100:103], v98 offset:" R0 "\n\t"                                         \
+    "ds_read_b128 v[104:107], v98 offset:" R1 "\n\t"                                         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+    "s_branch Lgo" #KB "_%=\n"
+
+typedef int sw_i32x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 wbase, u32 voff, u32 z1, u32 g0, u32 tm1, u32 expoff,
+                                             const unsigned char* cbase, u32 hbase, int hoff4, u32 cnt_addr, u32 cons_addr,
+                                             u32 right_addr, u32 prog_addr, int UT, int k1, int k2, int kc, int kr, int hmask,
+                                             sw_i32x4p erc, int (&polls)[2]) {
+    int status;
+    asm volatile(
+        "s_setprio 3\n\t"
+        "s_mov_b32 %[status], 0\n\t"
+        "s_mov_b32 s84, 0\n\t"
+        "s_mov_b32 s94, 0\n\t"
+        "s_mov_b32 s95, 0\n\t"
+        "s_mov_b32 s88, 1\n\t"
+        "s_mov_b32 s90, 0\n\t"
+        "s_mov_b32 s75, 0\n\t"
+        "s_mov_b32 s76, %[e0]\n\t"
+        "s_mov_b32 s77, %[e1]\n\t"
+        "s_mov_b32 s78, %[e2]\n\t"
+        "s_mov_b32 s79, %[e3]\n\t"
+        "s_and_b32 s91, %[hoff4], %[hmask]\n\t"
+        "s_mov_b64 s[92:93], %[cbase]\n\t"
+        "v_mov_b32 v96, %[voff]\n\t"
+        "v_mov_b32 v97, %[expoff]\n\t"
+        "v_mov_b32 v88, %[cntaddr]\n\t"
+        "v_mov_b32 v89, %[consaddr]\n\t"
+        "v_mov_b32 v90, %[rightaddr]\n\t"
+        "v_mov_b32 v91, %[progaddr]\n\t"
+        "v_mov_b32 v115, %[g0]\n\t"               /* step 0: every lane holds its row-0 value */
+        "v_mov_b32 v118, %[tm1]\n\t"              /* t of step -1 */
+        "v_mov_b32 v121, %[z1]\n\t"               /* floor of step 1 */
+        "v_mov_b32 v80, 0\n\t"
+        "v_mov_b32 v81, 0\n\t"
+        "v_mov_b32 v82, 0\n\t"
+        "v_mov_b32 v83, 0\n\t"
+        "v_mov_b32 v84, 0\n\t"
+        "s_nop 4\n\t"
+        "global_load_dwordx4 v[76:79], v96, s[92:93] offset:0\n\t"     /* the block before the first: its last byte is step 0 */
+        "global_load_dwordx4 v[64:67], v96, s[92:93] offset:16\n\t"
+        "global_load_dwordx4 v[68:71], v96, s[92:93] offset:32\n\t"
+        "global_load_dwordx4 v[72:75], v96, s[92:93] offset:48\n\t"
+        "s_add_u32 s92, s92, 64\n\t"
+        "s_addc_u32 s93, s93, 0\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_perm_b32 v63, %[phi], %[plo], v79\n"
+        "Lchunk_%=:\n\t"
+        PP_BPCHECK("A")
+        "v_add_u32 v126, s90, %[wbase]\n\t"
+        "v_mov_b32 v98, %[hbase]\n\t"
+        "v_add_u32 v98, s91, v98\n\t"
+        "s_add_i32 s91, s91, 256\n\t"
+        "s_and_b32 s91, s91, %[hmask]\n\t"
+        "v_mov_b32 v99, %[hbase]\n\t"
+        "v_add_u32 v99, s91, v99\n\t"
+        PP_BLOCK(0, "v63", "v122", "v123", "v124", "v125", "v64", "v65", "v66", "v67", "v[76:79]", "0", "0", "16", "32", "48",
+                 "32", "48", "v98 offset:64", "v98 offset:80", "3", "3", "3", "")
+        PP_BLOCK(16, "v125", "v60", "v61", "v62", "v63", "v68", "v69", "v70", "v71", "v[64:67]", "16", "64", "80", "96", "112",
+                 "96", "112", "v98 offset:128", "v98 offset:144", "3", "3", "5", PP_BPFETCH)
+        PP_BPCHECK("B")
+        PP_BLOCK(32, "v63", "v122", "v123", "v124", "v125", "v72", "v73", "v74", "v75", "v[68:71]", "32", "128", "144", "160", "176",
+                 "160", "176", "v98 offset:192", "v98 offset:208", "3", "3", "3", "")
+        PP_BLOCK(48, "v125", "v60", "v61", "v62", "v63", "v76", "v77", "v78", "v79", "v[72:75]", "48", "192", "208", "224", "240",
+                 "224", "240", "v99", "v99 offset:16", "3", "3", "5", PP_BPFETCH)
+        "s_add_i32 s90, s90, 256\n\t"
+        "s_and_b32 s90, s90, 1023\n\t"
+        "s_add_i32 s75, s75, 256\n\t"
+        "s_add_u32 s92, s92, 64\n\t"
+        "s_addc_u32 s93, s93, 0\n\t"
+        "s_branch Lchunk_%=\n"
+        PP_SLOW(0, "0", "16") PP_SLOW(16, "64", "80") PP_SLOW(32, "128", "144") PP_SLOW(48, "192", "208")
+        "Lbpfail_%=:\n\t"
+        "s_mov_b32 %[status], 2\n"
+        "Lexit_%=:\n\t"
+        "s_setprio 0\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        "s_mov_b32 %[nbp], s94\n\t"
+        "s_mov_b32 %[nhalo], s95\n\t"
+        : [status] "=&s"(status), [nbp] "=&s"(polls[0]), [nhalo] "=&s"(polls[1])
+        : [plo] "v"(plo), [phi] "v"(phi), [ngap] "v"(ngap_v), [wbase] "v"(wbase), [voff] "v"(voff), [z1] "v"(z1), [g0] "v"(g0), [tm1] "v"(tm1),
+          [expoff] "v"(expoff), [cbase] "s"(cbase), [hbase] "s"(hbase), [hoff4] "s"(hoff4), [cntaddr] "s"(cnt_addr), [consaddr] "s"(cons_addr),
+          [rightaddr] "s"(right_addr), [progaddr] "s"(prog_addr), [ut] "s"(UT), [k1] "s"(k1), [k2] "s"(k2), [kc] "s"(kc), [kr] "s"(kr),
+          [hmask] "s"(hmask), [e0] "s"(erc.x), [e1] "s"(erc.y), [e2] "s"(erc.z), [e3] "s"(erc.w)
+        : "vcc", "scc", "memory", "s75", "s76", "s77", "s78", "s79", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
+          "s95", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
+          "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v96", "v97", "v98", "v99", "v100",
+          "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
+          "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
+    return status;
+}
+
+
+// =================================================================================================
 // Consumer: four matrix rows per asm statement, hand-scheduled (literal registers are temporaries
 // of the statement only).  Per row: s' (cmp+cndmask), diagonal candidate (DPP-fused add), z, H,
 // three compares + three selects for P (serial_smithW.c:204-234: first of DIAGONAL, UP, LEFT that
@@ -612,7 +855,7 @@ __device__ __forceinline__ void consumer_block16_h64(const u32 (&g)[SY_U + 1], u
 }
 
 template <typename HT, int NS, int NC>
-__global__ void __launch_bounds__(NS == 1 ? 64 * 12 : 64 * (NS * (1 + NC) + 2))   // NS == 1: up to 12 waves, the spare ones are extra importers
+__global__ void __launch_bounds__(NS == 1 ? 768 : 64 * (NS * (1 + NC) + 2))   // NS == 1: 12 waves, SIMD 0 belongs to the producer (3 waves per SIMD: 168 VGPRs)
 sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsigned char* bpad, FillParams p) {
     __shared__ SysLds<NS> lds;
     const int lane = threadIdx.x & 63;
@@ -623,7 +866,11 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
     const int ngroups = (p.nstrips + NS - 1) / NS;
     const u64 tag_base = p.tag_base;
     const int64_t estride = p.rows + 1;
-    const int phib = p.phi_base;
+    // perm producer: eligible on the host side (score range -> gbias != 0) AND an alphabet of at most 7 letters (found on
+    // the device by sw_pad_b); it always uses the fast step numbering
+    const bool perm = (p.gbias != 0) && (*(const unsigned int*)(p.atab + 256) <= 7u) && !(p.debug_flags & 16);
+    const int phib = perm ? p.nstrips - 1 : p.phi_base;
+    const int gb = perm ? (int)p.gbias : 0;       // carried by every G value
     auto u_total = [&](int s) { return (rows + SY_W + phi_of(s, phib) + SY_U - 1) / SY_U * SY_U; };  // local steps 1..u_total
 
     const unsigned char* const seq_a0 = seq_a; const unsigned char* const seq_b0 = seq_b; const unsigned char* const bpad0 = bpad;
@@ -651,6 +898,8 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
         bpad = bpad0 + pair * p0.bpad_pstride;
         p.bpad16 = p0.bpad16 + pair * p0.bpad_pstride;
         p.edge = p0.edge + pair * p0.edge_pstride;
+        p.edge4 = p0.edge4 + pair * p0.edge4_pstride;
+        p.bcode = p0.bcode + pair * p0.bpad_pstride;
         p.result_key = p0.result_key + pair;
         p.H = p0.H ? (void*)((char*)p0.H + pair * p0.hp_pstride * (int64_t)sizeof(HT)) : nullptr;
         p.P = p0.P ? (int32_t*)((char*)p0.P + pair * p0.hp_pstride * (int64_t)p0.p_bytes) : nullptr;
@@ -690,20 +939,27 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
             return p.top_gran ? lds.topv[ls_][lane_] : (p.top ? p.top[j_] : 0);
         };
 
-        // Role of each wave.  Waves are dealt to the four SIMDs cyclically, so waves w, w+4, w+8 share a
-        // SIMD: with NS == 2 the two mostly-sleeping helper waves take slots 4 and 5, i.e. the SIMDs of the
-        // two producers (waves 0 and 1), and every consumer wave shares at most with one producer.
-        // With NS == 1 the helpers take waves 4 and 8 (the producer's SIMD), so no consumer shares with it.
+        // Role of each wave.  Waves are dealt to the four SIMDs cyclically, so waves w, w+4, w+8, w+12 share a SIMD.
+        // A producer issues one instruction per ~4.5 clk, i.e. it fills the VALU pipe of its SIMD almost alone; measured
+        // (round 2): the same producer loop takes 12.0 ns per step alone on a SIMD and 20.8 ns beside a polling importer.
+        // NS == 1: the producer (wave 0) gets SIMD 0 for itself -- waves 4, 8, 12 go straight to the barrier and sleep
+        // there --, consumers, the exporter and the importers fill the other three SIMDs.
+        // NS == 2 (batches, VALU-bound anyway): the two helper waves take slots 4 and 5, the SIMDs of the two producers.
         constexpr int NWAVES = NS * (1 + NC) + 2;
         static_assert(NWAVES <= 16 && NC <= 8, "at most 1024 threads; four counter slots shared by up to two consumers each");
-        constexpr bool helpers_mid = (NS == 2 && NWAVES > 6);
-        constexpr bool helpers_s0 = (NS == 1 && NWAVES >= 9);
-        const int h_imp = (helpers_mid || helpers_s0) ? 4 : NWAVES - 2, h_exp = helpers_mid ? 5 : helpers_s0 ? 8 : NWAVES - 1;
-        // optional extra importers (launched as extra waves, NS == 1 only): several waves polling the same edge
-        // column cut the time a freshly exported row waits for the next polling load
-        const bool is_helper = (wave == h_imp || wave == h_exp || wave >= NWAVES);
-        const int cw = wave - NS - (wave > h_imp ? 1 : 0) - (wave > h_exp ? 1 : 0);  // consumer ordinal 0..NS*NC-1
-        if (wave < NS) {
+        enum { R_PROD, R_CONS, R_IMP, R_EXP, R_IDLE };
+        int role, cw = 0;
+        if constexpr (NS == 1) {
+            const int k = wave - 1 - (wave >> 2);   // ordinal among the waves off SIMD 0
+            role = (wave == 0) ? R_PROD : ((wave & 3) == 0) ? R_IDLE : (k < NC) ? R_CONS : (k == NC) ? R_EXP : R_IMP;
+            cw = k;
+        } else {
+            constexpr bool helpers_mid = (NWAVES > 6);
+            const int h_imp = helpers_mid ? 4 : NWAVES - 2, h_exp = helpers_mid ? 5 : NWAVES - 1;
+            role = (wave < NS) ? R_PROD : (wave == h_imp || wave >= NWAVES) ? R_IMP : (wave == h_exp) ? R_EXP : R_CONS;
+            cw = wave - NS - (wave > h_imp ? 1 : 0) - (wave > h_exp ? 1 : 0);  // consumer ordinal 0..NS*NC-1
+        }
+        if (role == R_PROD) {
             // ================================ producer ================================
             const int ls = wave, s = s0 + ls;
             asm volatile("; SW_PRODUCER_PATH_BEGIN ");
@@ -713,7 +969,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 const u32 j = (u32)s * SY_W + (u32)lane;
                 const bool jvalid = (int64_t)j <= p.cols;
                 const u32 a_l = (lane >= 1 && jvalid) ? (u32)seq_a[j - 1] : (u32)SY_ASENT;
-                const u32 G0v = jvalid ? (u32)(top_at(ls, lane, j) + ngap * (int)j) : 0u;  // row 0 in G-space
+                const u32 G0v = jvalid ? (u32)(gb + top_at(ls, lane, j) + ngap * (int)j) : (u32)gb;  // row 0 in G-space
                 const u32 mm_v = (u32)mm, xm_v = (u32)xm, ngap_v = (u32)ngap;
                 const bool lefthalo = (ls == 0);         // halo comes from the import ring
                 const bool has_right = (ls + 1 < nact);  // another producer reads my lane-63 column
@@ -739,7 +995,44 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 };
 
                 if (p.dbg && lane == 0) p.dbg[2 * s] = __builtin_amdgcn_s_memrealtime();
-                if (phib >= 0) {
+                if (perm) {
+                    // ---- perm producer (whole strip loop in one asm statement) ----
+                    // profile of this lane: score of its NEXT column's letter against every letter code (7: outside)
+                    const bool nvalid = (int64_t)j < p.cols;
+                    const u32 acode = nvalid ? (u32)p.atab[seq_a[j]] : 8u;
+                    u32 prof_lo = 0, prof_hi = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) prof_lo |= ((u32)(unsigned char)(signed char)((u32)c == acode ? mm : xm)) << (8 * c);
+#pragma unroll
+                    for (int c = 4; c < 7; ++c) prof_hi |= ((u32)(unsigned char)(signed char)((u32)c == acode ? mm : xm)) << (8 * (c - 4));
+                    prof_hi |= ((u32)(unsigned char)(signed char)SW_PERM_PAD) << 24;
+                    const u32 wbase = ringbase + (u32)lane * (u32)SY_LSTR;
+                    // lane l, local step u scores b[u - phi - l] (the row BELOW its own): byte offset of the window that
+                    // ends at step 0; the scalar base moves with the blocks
+                    const unsigned char* cb = p.bcode + (p.bfront - 78 - phi);
+                    const u32 voff = 63u - (u32)lane;
+                    const u32 z1 = (u32)(gb + ngap * (1 - phi + s * SY_W));       // floor of local step 1
+                    const int k1 = lefthalo ? 2 * SY_U : 2 * SY_U - 1 + hoff;
+                    const int k2 = lefthalo ? rows + phi + 1 : left_total;
+                    const int kc = 30 - SY_R - phi;
+                    const int kr = (has_right ? -(SY_R + 1) + 16 : -SY_R - phi) - 32;
+                    const u32 expoff = (has_export && lane == 63) ? 0u : SY_OOB;
+                    const uint64_t eb = (uint64_t)(uintptr_t)(p.edge4 + (int64_t)s * p.e4stride);
+                    const sw_i32x4p erc = {(int)(u32)eb, (int)(u32)(eb >> 32), 0x7FFFFF00, 0x00020000};
+                    int polls[2];
+                    const int st = producer_perm(prof_lo, prof_hi, ngap_v, wbase, voff, z1, G0v, G0v + (u32)SW_PERM_PAD, expoff, cb, hbase, hoff * 4, cnt_addr,
+                                                 (u32)(size_t)&lds.cons_blk[ls][0], (u32)(size_t)(has_right ? right_cnt : &lds.never),
+                                                 (u32)(size_t)&lds.prod_u[ls], UT, k1, k2, kc, kr, hmask * 4 + 3, erc, polls);
+                    if (p.dbg && lane == 0) {
+                        p.dbg[2 * s + 1] = __builtin_amdgcn_s_memrealtime();
+                        p.dbg[4 * p.nstrips + 16 + 2 * s] = (u64)polls[0];
+                        p.dbg[4 * p.nstrips + 17 + 2 * s] = (u64)polls[1];
+                    }
+                    if (st) {
+                        __hip_atomic_store((gu32*)p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return;
+                    }
+                } else if (phib >= 0) {
                     // ---- fast producer (whole strip loop in one asm statement) ----
                     const u32 wbase = ringbase + (u32)lane * (u32)SY_LSTR;
                     const u32 voff = 2u * (u32)(p.bfront - phi - lane);           // byte offset of local step 1's character
@@ -833,7 +1126,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 }
             }
             asm volatile("; SW_PRODUCER_PATH_END");
-        } else if (!is_helper) {
+        } else if (role == R_CONS) {
             // ================================ consumer ================================
             const int ls = cw % NS, ci = cw / NS, s = s0 + ls;
             if (ls < nact && (p.debug_flags & 2)) {
@@ -854,7 +1147,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 const bool p8 = (p.p_bytes == 1);                 // compact predecessor matrix: one byte per cell
                 const u32 voffP = store_p ? j * (p8 ? 1u : 4u) : SY_OOB;
                 const int a_l = (lane >= 1 && jvalid) ? (int)seq_a[j - 1] : SY_ASENT;
-                const int cz = ngap * (int)j;
+                const int cz = gb + ngap * (int)j;
                 const int topj = jvalid ? top_at(ls, lane, j) : 0;
                 const int G0v = topj + (jvalid ? cz : 0);
                 HT* H = (HT*)p.H;
@@ -1018,13 +1311,82 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                     atomicMax(p.result_key, ((u64)(u32)bestv << 40) | (SW_KEY_IDX_MASK - idx));
                 }
             }
-        } else {
+        } else if (role != R_IDLE) {
             // ================================= helper ==================================
             // import: edge column of strip s0-1 (HBM granules; column 0 / row 0 synthesised) -> lds.halo,
             //         indexed by strip s0's local step: row t lives at entry (t + phi0 - 1) mod RH
             // export: lane-63 column of the group's last strip -> HBM granules for the next group
             const int slast = s0 + nact - 1;
             __builtin_amdgcn_s_setprio(2);  // short, latency-critical loops: ahead of the consumers on their SIMD
+            if (perm) {
+                // ---- perm path: the left group's last producer stored its lane-63 results itself, as 4-byte values that
+                // carry the launch tag, indexed by ITS local step; my strip's local step u needs its step u + 64.
+                // There is no exporter.  Steps above the matrix (rows <= 0) hold the row-0 value of the halo column.
+                const bool importer_w = (role == R_IMP || role == R_EXP);   // nothing to export here: one more importer
+                if (importer_w) {
+                    const int phi0 = phi_of(s0, phib);
+                    const u32 row0v = (u32)(gb + top_at(0, 0, (int64_t)s0 * SY_W) + ngap * s0 * SY_W);
+                    const int ulast = rows + phi0;                 // last local step whose halo is a matrix row
+                    const u32 tag = (u32)gb >> 24;
+                    const u32* e4 = (s0 > 0) ? p.edge4 + (int64_t)(s0 - 1) * p.e4stride : nullptr;
+                    int impu = 1;
+                    bool wide = true;
+                    Spin spin;
+                    while (impu <= ulast) {
+                        const int front = lds_load(&lds.halo_ready);
+                        if (front > 1) impu = max(impu, front);
+                        if (impu > ulast) break;
+                        int lim = min(ulast + 1, lds_load(&lds.prod_u[0]) + SY_RH - 2 * SY_U);   // steps < lim may be written
+                        int base = impu;
+                        auto windows = [&](auto NB) {
+                            constexpr int nbat = decltype(NB)::value;
+                            u32 vals[nbat];
+                            bool oks[nbat];
+#pragma unroll
+                            for (int b4 = 0; b4 < nbat; ++b4) {
+                                const int u = impu + b4 * 64 + lane;
+                                const int r = u - phi0;
+                                u32 v = row0v;
+                                bool ok = true;
+                                if (r > 0) {
+                                    if (s0 == 0) v = (u32)(gb + ngap * r + (p.left ? p.left[min(r, rows)] : 0));
+                                    else {
+                                        v = __hip_atomic_load((gu32*)(e4 + min(u, ulast) + 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        ok = (v >> 24) == tag;
+                                    }
+                                }
+                                vals[b4] = v;
+                                oks[b4] = ok && (u < lim);
+                            }
+                            const int front2 = lds_load(&lds.halo_ready);
+#pragma unroll
+                            for (int b4 = 0; b4 < nbat; ++b4) {
+                                const int u = impu + b4 * 64 + lane;
+                                const u64 okm = __ballot(oks[b4]);
+                                const int npre = (okm == ~0ull) ? 64 : __builtin_ctzll(~okm);
+                                if (base == impu + b4 * 64 && npre > 0) {
+                                    if (lane < npre && (front2 <= 1 || u >= front2))
+                                        __hip_atomic_store(&lds.halo[(u - 1) & (SY_RH - 1)], vals[b4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    base += npre;
+                                }
+                            }
+                        };
+                        if (wide) windows(std::integral_constant<int, 4>{});
+                        else windows(std::integral_constant<int, 1>{});
+                        wide = (base - impu) >= 64;
+                        if (base > impu) {
+                            asm volatile("" ::: "memory");
+                            if (p.dbg && lane == 0 && impu - phi0 <= rows / 2 && base - phi0 > rows / 2) p.dbg[2 * p.nstrips + 8 + 2 * grp] = __builtin_amdgcn_s_memrealtime();
+                            impu = base;
+                            __hip_atomic_fetch_max(&lds.halo_ready, impu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        } else if (spin.fail(p.abort_flag)) {
+                            return;
+                        }
+                    }
+                    lds_store(&lds.halo_ready, 0x7fffffff);
+                }
+                __builtin_amdgcn_s_setprio(0);
+            } else {
             const bool do_export = (slast + 1 < p.nstrips);
             const int phi0 = phi_of(s0, phib), phil = phi_of(slast, phib);
             const u32 halo_row0 = (u32)(top_at(0, 0, (int64_t)s0 * SY_W) + ngap * s0 * SY_W);
@@ -1042,7 +1404,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 ok = (gr >> 32) == (tag_base | (u64)r);
                 return (u32)gr;
             };
-            const bool importer = (wave == h_imp || wave >= NWAVES), exporter = (wave == h_exp);
+            const bool importer = (role == R_IMP), exporter = (role == R_EXP);
             while ((importer && imp <= rows) || (exporter && do_export && exp <= rows)) {
                 bool progressed = false;
                 if (importer && imp <= rows) {
@@ -1142,6 +1504,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
             __builtin_amdgcn_s_setprio(0);
             if (exporter && do_export) lds_store(&lds.exp_done, 0x7fffffff);
             if (importer) lds_store(&lds.halo_ready, 0x7fffffff);
+            }
         }
         __syncthreads();
     }
@@ -1157,14 +1520,57 @@ SW_INST(1, 2)
 SW_INST(1, 3)
 SW_INST(1, 4)
 SW_INST(1, 6)
-SW_INST(1, 8)
+SW_INST(1, 7)
 #undef SW_INST
+
+// Which byte values occur in a and b (all pairs of a batch): 256-bit presence map, OR-ed into present[8].
+__global__ void __launch_bounds__(256) sw_alpha_scan(const unsigned char* __restrict__ a, int64_t cols, int64_t a_pstride,
+                                                     const unsigned char* __restrict__ b, int64_t rows, int64_t b_pstride, int64_t npairs,
+                                                     unsigned int* __restrict__ present) {
+    __shared__ unsigned int seen[8];
+    if (threadIdx.x < 8) seen[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t per = cols + rows, total = per * npairs;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pair = i / per, k = i - pair * per;
+        const unsigned char ch = k < cols ? a[pair * a_pstride + k] : b[pair * b_pstride + (k - cols)];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) mine[w] |= ((ch >> 5) == w) ? (1u << (ch & 31)) : 0u;
+    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w) if (mine[w]) atomicOr(&seen[w], mine[w]);
+    __syncthreads();
+    if (threadIdx.x < 8 && seen[threadIdx.x]) atomicOr(&present[threadIdx.x], seen[threadIdx.x]);
+}
 
 // bpad[front + i] = b[i] (bytes, zero padded) and bpad16[front + i] = b[i] (16-bit, padded with the
 // never-matching 0x100): producer lane l reads b[u-phi-l-1] for steps that reach phi+63 rows above and
-// ~200 rows below the matrix (those cells are never stored).
-__global__ void sw_pad_b(const unsigned char* __restrict__ b, int64_t rows, int64_t front, int64_t b_pstride,
-                         unsigned char* __restrict__ bpad, unsigned short* __restrict__ bpad16, int64_t per) {
+// ~200 rows below the matrix (those cells are never stored).  bcode: the same as letter codes (rank of the byte
+// value among the values present, 7 outside the sequence); block (0,0) also publishes the code table atab.
+__global__ void __launch_bounds__(256) sw_pad_b(const unsigned char* __restrict__ b, int64_t rows, int64_t front, int64_t b_pstride,
+                                                unsigned char* __restrict__ bpad, unsigned short* __restrict__ bpad16,
+                                                unsigned char* __restrict__ bcode, const unsigned int* __restrict__ present,
+                                                unsigned char* __restrict__ atab, int64_t per) {
+    __shared__ unsigned char tab[256];
+    {
+        const int t = threadIdx.x;   // rank of byte value t among the present values
+        int rank = 0, nletters = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const unsigned int m = present[w];
+            nletters += __popc(m);
+            if (w < (t >> 5)) rank += __popc(m);
+            else if (w == (t >> 5)) rank += __popc(m & ((1u << (t & 31)) - 1u));
+        }
+        const bool here = (present[t >> 5] >> (t & 31)) & 1u;
+        tab[t] = (here && nletters <= 7) ? (unsigned char)rank : (unsigned char)7;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            atab[t] = tab[t];
+            if (t == 0) *(unsigned int*)(atab + 256) = (unsigned int)nletters;
+        }
+    }
+    __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t pair = blockIdx.y;  // batch: one padded copy per problem
     if (i < per) {
@@ -1172,6 +1578,7 @@ __global__ void sw_pad_b(const unsigned char* __restrict__ b, int64_t rows, int6
         const unsigned char ch = in ? b[pair * b_pstride + i - front] : (unsigned char)0;
         bpad[pair * per + i] = ch;
         bpad16[pair * per + i] = in ? (unsigned short)ch : (unsigned short)0x100;  // 0x100 never equals a character
+        bcode[pair * per + i] = in ? tab[ch] : (unsigned char)7;
     }
 }
 

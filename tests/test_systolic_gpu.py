@@ -143,3 +143,28 @@ def test_stalled_strip_times_out_and_context_recovers(engine, oracle, swamd):
     finally:
         engine.set_option("debug_flags", 0)
     check_against_oracle(engine, oracle, a, b)
+
+
+@pytest.mark.parametrize("nletters", [1, 2, 5, 7, 8, 20])
+def test_alphabet_sizes_pick_the_producer(engine, oracle, nletters):
+    """Up to 7 distinct letters run the perm producer (letter codes + v_perm profile), more fall back to the
+    character-compare producer: same matrices either way."""
+    rng = np.random.default_rng(100 + nletters)
+    letters = rng.choice(np.arange(33, 127), size=nletters, replace=False).astype(np.uint8)
+    a = letters[rng.integers(0, nletters, 1500)]
+    b = letters[rng.integers(0, nletters, 900)]
+    check_against_oracle(engine, oracle, a, b)
+    check_against_oracle(engine, oracle, a, b, scores=(5, 2, -3))     # positive mismatch
+    check_against_oracle(engine, oracle, a, b, scores=(100, -90, -20))  # scores beyond a signed byte: character-compare producer
+
+
+@pytest.mark.parametrize("cols,rows", [(1000, 700), (63, 16), (4200, 1300), (130, 1029), (1, 1), (64, 200)])
+def test_character_compare_producers_still_exact(engine, oracle, cols, rows):
+    """debug bit 4 switches the perm producer off: the round-1 producers (fast / generic) behind the same tests."""
+    a, b = oracle.generate(cols, rows, 33)
+    engine.set_option("debug_flags", 16)
+    try:
+        check_against_oracle(engine, oracle, a, b)
+        check_against_oracle(engine, oracle, a, b, scores=(3, 1, -2))
+    finally:
+        engine.set_option("debug_flags", 0)
