@@ -61,7 +61,7 @@ template <int NS>
 struct SysLds {
     __attribute__((aligned(16))) unsigned char ring[NS][64 * SY_LSTR];
     __attribute__((aligned(16))) u32 halo[SY_RH];      // edge column imported from the previous workgroup
-    __attribute__((aligned(16))) int cons_blk[NS][4];  // latest completed 16-row block per consumer (-1 none; unused INT_MAX)
+    __attribute__((aligned(16))) int cons_blk[NS][8];  // latest completed 16-row block per consumer (-1 none; unused INT_MAX)
     int prod_u[NS];   // completed local steps of each producer
     int halo_ready;   // imported halo: every local step (strip s0's numbering) < halo_ready is in halo[]
     int exp_done;     // exported edge rows: every row <= exp_done is in HBM
@@ -257,10 +257,12 @@ __device__ __forceinline__ int phi_of(int s, int phi_base) { return phi_base >= 
 // Ring back-pressure, every 32 steps: my consumers (four counters) and my right-hand reader (the next producer or
 // the exporter) must be done with the slots of the coming 32 steps.  The counters were fetched from LDS during the
 // block before (SF_BPFETCH: no LDS round trip on the fast path); only a failed check re-reads them and polls.
-#define SF_BPFETCH "ds_read_b128 v[60:63], v57\n\tds_read_b32 v97, v58\n\t"
+#define SF_BPFETCH "ds_read_b128 v[60:63], v57\n\tds_read_b128 v[52:55], v57 offset:16\n\tds_read_b32 v97, v58\n\t"
 #define SF_BPCHECK(T)                                                                         \
-    "v_min_i32 v116, v60, v61\n\t"                                                           \
-    "v_min3_i32 v116, v116, v62, v63\n\t"                                                    \
+    "v_min3_i32 v116, v60, v61, v62\n\t"                                                     \
+    "v_min3_i32 v117, v63, v52, v53\n\t"                                                     \
+    "v_min3_i32 v116, v116, v54, v55\n\t"                                                    \
+    "v_min_i32 v116, v116, v117\n\t"                                                         \
     "s_mov_b32 s89, 0\n\t"                                                                   \
     "v_readfirstlane_b32 s86, v97\n\t"                                                       \
     "v_readfirstlane_b32 s85, v116\n"                                                        \
@@ -280,10 +282,13 @@ __device__ __forceinline__ int phi_of(int s, int phi_base) { return phi_base >= 
     "s_cmp_lt_u32 s89, 0x1000000\n\t"                                                        \
     "s_cbranch_scc0 Lbpfail_%=\n\t"                                                          \
     "ds_read_b128 v[116:119], v57\n\t"                                                       \
+    "ds_read_b128 v[52:55], v57 offset:16\n\t"                                               \
     "ds_read_b32 v120, v58\n\t"                                                              \
     "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+    "v_min3_i32 v116, v116, v117, v118\n\t"                                                  \
+    "v_min3_i32 v117, v119, v52, v53\n\t"                                                    \
+    "v_min3_i32 v116, v116, v54, v55\n\t"                                                    \
     "v_min_i32 v116, v116, v117\n\t"                                                         \
-    "v_min3_i32 v116, v116, v118, v119\n\t"                                                  \
     "s_nop 0\n\t"                                                                            \
     "v_readfirstlane_b32 s85, v116\n\t"                                                      \
     "v_readfirstlane_b32 s86, v120\n\t"                                                      \
@@ -342,6 +347,10 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
         "v_mov_b32 v61, 0\n\t"
         "v_mov_b32 v62, 0\n\t"
         "v_mov_b32 v63, 0\n\t"
+        "v_mov_b32 v52, 0\n\t"
+        "v_mov_b32 v53, 0\n\t"
+        "v_mov_b32 v54, 0\n\t"
+        "v_mov_b32 v55, 0\n\t"
         "v_mov_b32 v97, 0\n\t"
         "s_nop 4\n\t"
         "global_load_dwordx4 v[64:67], v96, s[92:93] offset:0\n\t"
@@ -387,7 +396,7 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
           [cbase] "s"(cbase), [hbase] "s"(hbase), [hoff4] "s"(hoff4), [cntaddr] "s"(cnt_addr), [consaddr] "s"(cons_addr),
           [rightaddr] "s"(right_addr), [progaddr] "s"(prog_addr), [ut] "s"(UT), [k1] "s"(k1), [k2] "s"(k2), [kc] "s"(kc), [kr] "s"(kr), [hmask] "s"(hmask)
         : "vcc", "scc", "memory", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95",
-          "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v97", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
+          "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v97", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75",
           "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91",
           "v92", "v93", "v94", "v95", "v96", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",
           "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123",
@@ -490,11 +499,13 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
     "s_add_i32 s88, s88, 16\n\t"                                                             \
     "s_cmp_gt_i32 s88, %[ut]\n\t"                                                            \
     "s_cbranch_scc1 Lexit_%=\n\t"
-#define PP_BPFETCH "ds_read_b128 v[80:83], v89\n\tds_read_b32 v84, v90\n\t"
+#define PP_BPFETCH "ds_read_b128 v[80:83], v89\n\tds_read_b128 v[52:55], v89 offset:16\n\tds_read_b32 v84, v90\n\t"
 #define PP_BPCHECK(T)                                                                         \
     "s_waitcnt lgkmcnt(1)\n\t"                                                               \
-    "v_min_i32 v92, v80, v81\n\t"                                                            \
-    "v_min3_i32 v92, v92, v82, v83\n\t"                                                      \
+    "v_min3_i32 v92, v80, v81, v82\n\t"                                                      \
+    "v_min3_i32 v93, v83, v52, v53\n\t"                                                      \
+    "v_min3_i32 v92, v92, v54, v55\n\t"                                                      \
+    "v_min_i32 v92, v92, v93\n\t"                                                            \
     "s_mov_b32 s89, 0\n\t"                                                                   \
     "v_readfirstlane_b32 s86, v84\n\t"                                                       \
     "v_readfirstlane_b32 s85, v92\n"                                                         \
@@ -514,10 +525,13 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
     "s_cmp_lt_u32 s89, 0x1000000\n\t"                                                        \
     "s_cbranch_scc0 Lbpfail_%=\n\t"                                                          \
     "ds_read_b128 v[80:83], v89\n\t"                                                         \
+    "ds_read_b128 v[52:55], v89 offset:16\n\t"                                               \
     "ds_read_b32 v84, v90\n\t"                                                               \
     "s_waitcnt lgkmcnt(0)\n\t"                                                               \
-    "v_min_i32 v92, v80, v81\n\t"                                                            \
-    "v_min3_i32 v92, v92, v82, v83\n\t"                                                      \
+    "v_min3_i32 v92, v80, v81, v82\n\t"                                                      \
+    "v_min3_i32 v93, v83, v52, v53\n\t"                                                      \
+    "v_min3_i32 v92, v92, v54, v55\n\t"                                                      \
+    "v_min_i32 v92, v92, v93\n\t"                                                            \
     "s_nop 0\n\t"                                                                            \
     "v_readfirstlane_b32 s85, v92\n\t"                                                       \
     "v_readfirstlane_b32 s86, v84\n\t"                                                       \
@@ -553,7 +567,7 @@ typedef int sw_i32x4p __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 wbase, u32 voff, u32 z1, u32 g0, u32 tm1, u32 expoff,
                                              const unsigned char* cbase, u32 hbase, int hoff4, u32 cnt_addr, u32 cons_addr,
                                              u32 right_addr, u32 prog_addr, int UT, int k1, int k2, int kc, int kr, int hmask,
-                                             sw_i32x4p erc, int (&polls)[2]) {
+                                             sw_i32x4p erc, int cinc, int (&polls)[2]) {
     int status;
     asm volatile(
         "s_setprio 3\n\t"
@@ -583,6 +597,10 @@ __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 w
         "v_mov_b32 v81, 0\n\t"
         "v_mov_b32 v82, 0\n\t"
         "v_mov_b32 v83, 0\n\t"
+        "v_mov_b32 v52, 0\n\t"
+        "v_mov_b32 v53, 0\n\t"
+        "v_mov_b32 v54, 0\n\t"
+        "v_mov_b32 v55, 0\n\t"
         "v_mov_b32 v84, 0\n\t"
         "s_nop 4\n\t"
         "global_load_dwordx4 v[76:79], v96, s[92:93] offset:0\n\t"     /* the block before the first: its last byte is step 0 */
@@ -605,16 +623,16 @@ __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 w
         PP_BLOCK(0, "v63", "v122", "v123", "v124", "v125", "v64", "v65", "v66", "v67", "v[76:79]", "0", "0", "16", "32", "48",
                  "32", "48", "v98 offset:64", "v98 offset:80", "3", "3", "3", "")
         PP_BLOCK(16, "v125", "v60", "v61", "v62", "v63", "v68", "v69", "v70", "v71", "v[64:67]", "16", "64", "80", "96", "112",
-                 "96", "112", "v98 offset:128", "v98 offset:144", "3", "3", "5", PP_BPFETCH)
+                 "96", "112", "v98 offset:128", "v98 offset:144", "3", "3", "6", PP_BPFETCH)
         PP_BPCHECK("B")
         PP_BLOCK(32, "v63", "v122", "v123", "v124", "v125", "v72", "v73", "v74", "v75", "v[68:71]", "32", "128", "144", "160", "176",
                  "160", "176", "v98 offset:192", "v98 offset:208", "3", "3", "3", "")
         PP_BLOCK(48, "v125", "v60", "v61", "v62", "v63", "v76", "v77", "v78", "v79", "v[72:75]", "48", "192", "208", "224", "240",
-                 "224", "240", "v99", "v99 offset:16", "3", "3", "5", PP_BPFETCH)
+                 "224", "240", "v99", "v99 offset:16", "3", "3", "6", PP_BPFETCH)
         "s_add_i32 s90, s90, 256\n\t"
         "s_and_b32 s90, s90, 1023\n\t"
         "s_add_i32 s75, s75, 256\n\t"
-        "s_add_u32 s92, s92, 64\n\t"
+        "s_add_u32 s92, s92, %[cinc]\n\t"
         "s_addc_u32 s93, s93, 0\n\t"
         "s_branch Lchunk_%=\n"
         PP_SLOW(0, "0", "16") PP_SLOW(16, "64", "80") PP_SLOW(32, "128", "144") PP_SLOW(48, "192", "208")
@@ -629,10 +647,10 @@ __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 w
         : [plo] "v"(plo), [phi] "v"(phi), [ngap] "v"(ngap_v), [wbase] "v"(wbase), [voff] "v"(voff), [z1] "v"(z1), [g0] "v"(g0), [tm1] "v"(tm1),
           [expoff] "v"(expoff), [cbase] "s"(cbase), [hbase] "s"(hbase), [hoff4] "s"(hoff4), [cntaddr] "s"(cnt_addr), [consaddr] "s"(cons_addr),
           [rightaddr] "s"(right_addr), [progaddr] "s"(prog_addr), [ut] "s"(UT), [k1] "s"(k1), [k2] "s"(k2), [kc] "s"(kc), [kr] "s"(kr),
-          [hmask] "s"(hmask), [e0] "s"(erc.x), [e1] "s"(erc.y), [e2] "s"(erc.z), [e3] "s"(erc.w)
+          [hmask] "s"(hmask), [e0] "s"(erc.x), [e1] "s"(erc.y), [e2] "s"(erc.z), [e3] "s"(erc.w), [cinc] "s"(cinc)
         : "vcc", "scc", "memory", "s75", "s76", "s77", "s78", "s79", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
-          "s95", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
-          "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v96", "v97", "v98", "v99", "v100",
+          "s95", "v52", "v53", "v54", "v55", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
+          "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v96", "v97", "v98", "v99", "v100",
           "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
           "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
     return status;
@@ -728,29 +746,38 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
 #else
 #define CB_POLP(POL) POL
 #endif
-#define CB_H(POL, K, G)                                                                            \
+#ifdef CB_NOSTORE
+#define CB_ST(X) ""
+#else
+#define CB_ST(X) X
+#endif
+// (the x-macros take complete operand strings, so that the same text serves the one-block statement -- ring values
+//  and buffer descriptors as compiler operands -- and the whole-loop statement -- literal registers)
+#define CB_Hx(POL, K, GOP, RH)                                                                \
     "v_add_u32 %[z], %[z], %[ngap]\n\t"                                                      \
-    "v_sub_u32 v" #K ", %[" G "], %[z]\n\t"                                                   \
-    "buffer_store_dword v" #K ", %[voffH], %[rH], s81 offen" CB_POLH(POL) "\n\t"                             \
+    "v_sub_u32 v" #K ", " GOP ", %[z]\n\t"                                                    \
+    CB_ST("buffer_store_dword v" #K ", %[voffH], " RH ", s81 offen" CB_POLH(POL) "\n\t")      \
     "s_add_u32 s81, s81, %[strideH]\n\t"
+#define CB_H(POL, K, G) CB_Hx(POL, K, "%[" G "]", "%[rH]")
 // int64 H: the score is never negative, so the high dword is a zero register paired with each H register
-#define CB_H64(POL, K, K1, G)                                                                 \
+#define CB_H64x(POL, K, K1, GOP, RH)                                                          \
     "v_add_u32 %[z], %[z], %[ngap]\n\t"                                                      \
-    "v_sub_u32 v" #K ", %[" G "], %[z]\n\t"                                                   \
+    "v_sub_u32 v" #K ", " GOP ", %[z]\n\t"                                                    \
     "v_mov_b32 v" #K1 ", 0\n\t"                                                              \
-    "buffer_store_dwordx2 v[" #K ":" #K1 "], %[voffH], %[rH], s81 offen" POL "\n\t"           \
+    CB_ST("buffer_store_dwordx2 v[" #K ":" #K1 "], %[voffH], " RH ", s81 offen" POL "\n\t")   \
     "s_add_u32 s81, s81, %[strideH]\n\t"
-#define CB_PRED(G, UP, DD, M1, M3)                                                            \
-    "v_cmp_eq_u32_e64 " M1 ", %[" UP "], %[" G "]\n\t"                                       \
-    "v_cmp_eq_u32_e64 " M3 ", " DD ", %[" G "]\n\t"
-#define CB_SEL(POL, PST, HK, PI, M1, M3)                                                                \
+#define CB_H64(POL, K, K1, G) CB_H64x(POL, K, K1, "%[" G "]", "%[rH]")
+#define CB_PREDx(GOP, UPOP, DD, M1, M3)                                                       \
+    "v_cmp_eq_u32_e64 " M1 ", " UPOP ", " GOP "\n\t"                                         \
+    "v_cmp_eq_u32_e64 " M3 ", " DD ", " GOP "\n\t"
+#define CB_SELx(POL, PST, HK, PI, M1, M3, RP)                                                 \
     "v_cmp_eq_u32_e32 vcc, 0, " HK "\n\t"                                                    \
     "v_cndmask_b32_e64 " PI ", 2, 1, " M1 "\n\t"                                             \
     "v_cndmask_b32_e64 " PI ", " PI ", 3, " M3 "\n\t"                                        \
     "v_cndmask_b32_e64 " PI ", " PI ", 0, vcc\n\t"                                           \
-    PST " " PI ", %[voff], %[rP], s80 offen" CB_POLP(POL) "\n\t"                                             \
+    CB_ST(PST " " PI ", %[voff], " RP ", s80 offen" CB_POLP(POL) "\n\t")                      \
     "s_add_u32 s80, s80, %[stride]\n\t"
-#define CB_GROUP(POL, PST, CH, U, G0, G1, G2, G3, H0, H1, H2, H3)                                       \
+#define CB_GROUPx(POL, PST, CH, U, G0, G1, G2, G3, H0, H1, H2, H3, RP)                        \
     "v_cmp_eq_u32_sdwa s[60:61], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_0\n\t"            \
     "v_cmp_eq_u32_sdwa s[62:63], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_1\n\t"            \
     "v_cmp_eq_u32_sdwa s[64:65], %[a], " CH " src0_sel:DWORD src1_sel:BYTE_2\n\t"            \
@@ -759,18 +786,20 @@ __device__ __forceinline__ Rows4 consumer_rows4(u32 U, u32 G0, u32 G1, u32 G2, u
     "v_cndmask_b32_e64 v117, %[xm], %[mm], s[62:63]\n\t"                                     \
     "v_cndmask_b32_e64 v118, %[xm], %[mm], s[64:65]\n\t"                                     \
     "v_cndmask_b32_e64 v119, %[xm], %[mm], s[66:67]\n\t"                                     \
-    "v_add_u32_dpp v120, %[" U "], v116 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"  \
-    "v_add_u32_dpp v121, %[" G0 "], v117 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
-    "v_add_u32_dpp v122, %[" G1 "], v118 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
-    "v_add_u32_dpp v123, %[" G2 "], v119 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
-    CB_PRED(G0, U, "v120", "s[60:61]", "s[62:63]")                                            \
-    CB_PRED(G1, G0, "v121", "s[64:65]", "s[66:67]")                                           \
-    CB_SEL(POL, PST, H0, "v124", "s[60:61]", "s[62:63]")                                                \
-    CB_PRED(G2, G1, "v122", "s[68:69]", "s[70:71]")                                           \
-    CB_SEL(POL, PST, H1, "v125", "s[64:65]", "s[66:67]")                                                \
-    CB_PRED(G3, G2, "v123", "s[72:73]", "s[74:75]")                                           \
-    CB_SEL(POL, PST, H2, "v126", "s[68:69]", "s[70:71]")                                                \
-    CB_SEL(POL, PST, H3, "v127", "s[72:73]", "s[74:75]")
+    "v_add_u32_dpp v120, " U ", v116 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"  \
+    "v_add_u32_dpp v121, " G0 ", v117 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+    "v_add_u32_dpp v122, " G1 ", v118 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+    "v_add_u32_dpp v123, " G2 ", v119 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+    CB_PREDx(G0, U, "v120", "s[60:61]", "s[62:63]")                                           \
+    CB_PREDx(G1, G0, "v121", "s[64:65]", "s[66:67]")                                          \
+    CB_SELx(POL, PST, H0, "v124", "s[60:61]", "s[62:63]", RP)                                 \
+    CB_PREDx(G2, G1, "v122", "s[68:69]", "s[70:71]")                                          \
+    CB_SELx(POL, PST, H1, "v125", "s[64:65]", "s[66:67]", RP)                                 \
+    CB_PREDx(G3, G2, "v123", "s[72:73]", "s[74:75]")                                          \
+    CB_SELx(POL, PST, H2, "v126", "s[68:69]", "s[70:71]", RP)                                 \
+    CB_SELx(POL, PST, H3, "v127", "s[72:73]", "s[74:75]", RP)
+#define CB_GROUP(POL, PST, CH, U, G0, G1, G2, G3, H0, H1, H2, H3)                             \
+    CB_GROUPx(POL, PST, CH, "%[" U "]", "%[" G0 "]", "%[" G1 "]", "%[" G2 "]", "%[" G3 "]", H0, H1, H2, H3, "%[rP]")
 typedef int sw_i32x4 __attribute__((ext_vector_type(4)));
 #define CB_ASM(POL, PST) \
     asm volatile( \
@@ -854,6 +883,128 @@ __device__ __forceinline__ void consumer_block16_h64(const u32 (&g)[SY_U + 1], u
     else { CB_ASM64("", "buffer_store_dword"); }
 }
 
+// =================================================================================================
+// Consumer, the WHOLE loop over a wave's full 16-row blocks in one asm statement (int32 H).  hipcc's own code around
+// the one-block statement -- SGPR spills through v_readlane, 64-bit pointer arithmetic, the wrap test of the ring reads
+// -- made a block cost 1.4 us where its ~300 instructions need 0.6 (measured round 2: six consumers could not keep up
+// with a producer running 18 ns per row).  Per block here: poll the producer's progress, 17 ring reads along the skew
+// (base + immediate when no lane wraps inside the block, else per-entry masked addresses), the block body, arg-max
+// bookkeeping, publish, advance descriptors / pointers by NC blocks.
+// literal registers: v[80:96] ring values of rows r0-1..r0+15, v97..v99 scratch, v[100:127] as in the one-block
+// statement; s[44:47] / s[48:51] H / P buffer descriptors, s[52:53] row characters, s54 block index, s55 producer step
+// that completes the block, s56 scratch, s58 spin count, s59 ring entry of row r0-1 in lane 0 (unmasked)
+// =================================================================================================
+#define CL_RD(K, OFF) "ds_read_b32 v" #K ", v99 offset:" #OFF "\n\t"
+#define CL_RDW(K, I)                                                                          \
+    "v_add_u32 v98, " #I ", %[E]\n\t"                                                         \
+    "v_and_b32 v98, %[rmask], v98\n\t"                                                        \
+    "v_lshl_add_u32 v98, v98, 2, %[lanebase]\n\t"                                             \
+    "ds_read_b32 v" #K ", v98\n\t"
+#define CL_ASM(POL, PST)                                                                      \
+    asm volatile(                                                                             \
+        "s_mov_b32 %[status], 0\n\t"                                                          \
+        "s_mov_b32 s44, %[h0]\n\t" "s_mov_b32 s45, %[h1]\n\t" "s_mov_b32 s46, %[h2]\n\t" "s_mov_b32 s47, %[h3]\n\t" \
+        "s_mov_b32 s48, %[p0]\n\t" "s_mov_b32 s49, %[p1]\n\t" "s_mov_b32 s50, %[p2]\n\t" "s_mov_b32 s51, %[p3]\n\t" \
+        "s_mov_b64 s[52:53], %[cptr]\n\t"                                                     \
+        "s_mov_b32 s54, %[q0]\n\t"                                                            \
+        "s_mov_b32 s55, %[need0]\n\t"                                                         \
+        "s_mov_b32 s59, %[es0]\n"                                                             \
+        "Lcl_loop_%=:\n\t"                                                                    \
+        "s_mov_b32 s58, 0\n"                                                                  \
+        "Lcl_poll_%=:\n\t"                                                                    \
+        "ds_read_b32 v97, %[prodaddr]\n\t"                                                    \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                            \
+        "v_readfirstlane_b32 s56, v97\n\t"                                                    \
+        "s_cmp_ge_i32 s56, s55\n\t"                                                           \
+        "s_cbranch_scc1 Lcl_go_%=\n\t"                                                        \
+        "s_sleep 1\n\t"                                                                       \
+        "s_add_i32 s58, s58, 1\n\t"                                                           \
+        "s_cmp_lt_u32 s58, 0x1000000\n\t"                                                     \
+        "s_cbranch_scc1 Lcl_poll_%=\n\t"                                                      \
+        "s_mov_b32 %[status], 1\n\t"                                                          \
+        "s_branch Lcl_exit_%=\n"                                                              \
+        "Lcl_go_%=:\n\t"                                                                      \
+        "s_load_dwordx4 s[76:79], s[52:53], 0x0\n\t"                                          \
+        "s_and_b32 s56, s59, %[srmask]\n\t"                                                   \
+        "s_cmp_lt_u32 s56, %[nowrap]\n\t"                                                     \
+        "s_cbranch_scc0 Lcl_wrap_%=\n\t"                                                      \
+        "v_and_b32 v99, %[rmask], %[E]\n\t"                                                   \
+        "v_lshl_add_u32 v99, v99, 2, %[lanebase]\n\t"                                         \
+        CL_RD(80, 0) CL_RD(81, 4) CL_RD(82, 8) CL_RD(83, 12) CL_RD(84, 16) CL_RD(85, 20) CL_RD(86, 24) CL_RD(87, 28) CL_RD(88, 32) \
+        CL_RD(89, 36) CL_RD(90, 40) CL_RD(91, 44) CL_RD(92, 48) CL_RD(93, 52) CL_RD(94, 56) CL_RD(95, 60) CL_RD(96, 64)           \
+        "s_branch Lcl_have_%=\n"                                                              \
+        "Lcl_wrap_%=:\n\t"                                                                    \
+        CL_RDW(80, 0) CL_RDW(81, 1) CL_RDW(82, 2) CL_RDW(83, 3) CL_RDW(84, 4) CL_RDW(85, 5) CL_RDW(86, 6) CL_RDW(87, 7) CL_RDW(88, 8) \
+        CL_RDW(89, 9) CL_RDW(90, 10) CL_RDW(91, 11) CL_RDW(92, 12) CL_RDW(93, 13) CL_RDW(94, 14) CL_RDW(95, 15) CL_RDW(96, 16)       \
+        "Lcl_have_%=:\n\t"                                                                    \
+        "s_mov_b32 s81, 0\n\t"                                                                \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                            \
+        CB_Hx(POL, 100, "v81", "s[44:47]") CB_Hx(POL, 101, "v82", "s[44:47]") CB_Hx(POL, 102, "v83", "s[44:47]") CB_Hx(POL, 103, "v84", "s[44:47]") \
+        CB_Hx(POL, 104, "v85", "s[44:47]") CB_Hx(POL, 105, "v86", "s[44:47]") CB_Hx(POL, 106, "v87", "s[44:47]") CB_Hx(POL, 107, "v88", "s[44:47]") \
+        CB_Hx(POL, 108, "v89", "s[44:47]") CB_Hx(POL, 109, "v90", "s[44:47]") CB_Hx(POL, 110, "v91", "s[44:47]") CB_Hx(POL, 111, "v92", "s[44:47]") \
+        CB_Hx(POL, 112, "v93", "s[44:47]") CB_Hx(POL, 113, "v94", "s[44:47]") CB_Hx(POL, 114, "v95", "s[44:47]") CB_Hx(POL, 115, "v96", "s[44:47]") \
+        "v_max3_i32 v97, v100, v101, v102\n\t"                                                \
+        "v_max3_i32 v116, v103, v104, v105\n\t"                                               \
+        "v_max3_i32 v117, v106, v107, v108\n\t"                                               \
+        "v_max3_i32 v118, v109, v110, v111\n\t"                                               \
+        "v_max3_i32 v119, v112, v113, v114\n\t"                                               \
+        "v_max3_i32 v97, v97, v115, v116\n\t"                                                 \
+        "v_max3_i32 v97, v97, v117, v118\n\t"                                                 \
+        "v_max_i32 v97, v97, v119\n\t"                                                        \
+        "s_mov_b32 s80, 0\n\t"                                                                \
+        CB_GROUPx(POL, PST, "s76", "v80", "v81", "v82", "v83", "v84", "v100", "v101", "v102", "v103", "s[48:51]") \
+        CB_GROUPx(POL, PST, "s77", "v84", "v85", "v86", "v87", "v88", "v104", "v105", "v106", "v107", "s[48:51]") \
+        CB_GROUPx(POL, PST, "s78", "v88", "v89", "v90", "v91", "v92", "v108", "v109", "v110", "v111", "s[48:51]") \
+        CB_GROUPx(POL, PST, "s79", "v92", "v93", "v94", "v95", "v96", "v112", "v113", "v114", "v115", "s[48:51]") \
+        /* arg-max: the first of my blocks that reached the best value of my column (the row is re-read at the end) */ \
+        "v_cmp_gt_i32 vcc, v97, %[bestv]\n\t"                                                 \
+        "v_mov_b32 v98, s54\n\t"                                                              \
+        "s_nop 0\n\t"                                                                         \
+        "v_cndmask_b32 %[bestv], %[bestv], v97, vcc\n\t"                                      \
+        "v_cndmask_b32 %[bestblk], %[bestblk], v98, vcc\n\t"                                  \
+        "ds_write_b32 %[slotaddr], v98\n\t"        /* in LDS order behind this block's ring reads */ \
+        "v_add_u32 %[z], %[z], %[zstep]\n\t"                                                  \
+        "v_add_u32 %[E], %[E], %[estep]\n\t"                                                  \
+        "s_add_i32 s59, s59, %[sestep]\n\t"                                                   \
+        "s_add_i32 s55, s55, %[sestep]\n\t"                                                   \
+        "s_add_u32 s44, s44, %[bh0]\n\t"                                                      \
+        "s_addc_u32 s45, s45, %[bh1]\n\t"                                                     \
+        "s_add_u32 s48, s48, %[bp0]\n\t"                                                      \
+        "s_addc_u32 s49, s49, %[bp1]\n\t"                                                     \
+        "s_add_u32 s52, s52, %[sestep]\n\t"                                                   \
+        "s_addc_u32 s53, s53, 0\n\t"                                                          \
+        "s_add_i32 s54, s54, %[qstep]\n\t"                                                    \
+        "s_cmp_lt_i32 s54, %[qend]\n\t"                                                       \
+        "s_cbranch_scc1 Lcl_loop_%=\n"                                                        \
+        "Lcl_exit_%=:\n\t"                                                                    \
+        : [status] "=&s"(status), [z] "+v"(z), [E] "+v"(E), [bestv] "+v"(bestv), [bestblk] "+v"(bestblk)                                   \
+        : [a] "v"(a_l), [mm] "v"(mm_v), [xm] "v"(xm_v), [ngap] "v"(ngap_v), [voff] "v"(voff), [voffH] "v"(voffH), [lanebase] "v"(lanebase),  \
+          [zstep] "v"(zstep), [estep] "v"(estep), [prodaddr] "v"(prod_addr), [slotaddr] "v"(slot_addr), [rmask] "v"(rmask),                  \
+          [h0] "s"(rH.x), [h1] "s"(rH.y), [h2] "s"(rH.z), [h3] "s"(rH.w), [p0] "s"(rP.x), [p1] "s"(rP.y), [p2] "s"(rP.z), [p3] "s"(rP.w),     \
+          [cptr] "s"(chars), [q0] "s"(q0), [need0] "s"(need0), [es0] "s"(es0), [srmask] "s"((int)rmask), [nowrap] "s"(nowrap),               \
+          [sestep] "s"((int)estep), [bh0] "s"(bh0), [bh1] "s"(bh1), [bp0] "s"(bp0), [bp1] "s"(bp1), [qstep] "s"(qstep), [qend] "s"(qend),     \
+          [stride] "s"(stride), [strideH] "s"(strideH)                                                                                     \
+        : "vcc", "scc", "memory", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s58", "s59", "s60", \
+          "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",   \
+          "s80", "s81", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96",   \
+          "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",  \
+          "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
+// blocks q0, q0+qstep, ... < qend of one consumer wave; E: ring entry of row r0-1 for this lane (unmasked), advanced here
+template <bool NT, bool P8>
+__device__ __forceinline__ int consumer_loop32(u32& z, u32& E, u32& bestv, u32& bestblk, u32 lanebase, u32 a_l, u32 mm_v, u32 xm_v, u32 ngap_v,
+                                               u32 voff, u32 voffH, u32 zstep, u32 estep, u32 rmask, sw_i32x4 rH, sw_i32x4 rP, uint64_t blkH,
+                                               uint64_t blkP, u32 stride, u32 strideH, const unsigned char* chars, u32 prod_addr, u32 slot_addr,
+                                               int q0, int qend, int qstep, int need0, int es0) {
+    int status;
+    const int nowrap = (int)rmask + 1 - 63 - SY_U;   // ring entry (lane 0) below which no lane's 17 entries wrap
+    const int bh0 = (int)(u32)blkH, bh1 = (int)(u32)(blkH >> 32), bp0 = (int)(u32)blkP, bp1 = (int)(u32)(blkP >> 32);
+    if constexpr (NT && P8) { CL_ASM(" nt", "buffer_store_byte"); }
+    else if constexpr (NT) { CL_ASM(" nt", "buffer_store_dword"); }
+    else if constexpr (P8) { CL_ASM("", "buffer_store_byte"); }
+    else { CL_ASM("", "buffer_store_dword"); }
+    return status;
+}
+
 template <typename HT, int NS, int NC>
 __global__ void __launch_bounds__(NS == 1 ? 768 : 64 * (NS * (1 + NC) + 2))   // NS == 1: 12 waves, SIMD 0 belongs to the producer (3 waves per SIMD: 168 VGPRs)
 sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsigned char* bpad, FillParams p) {
@@ -904,7 +1055,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
         p.H = p0.H ? (void*)((char*)p0.H + pair * p0.hp_pstride * (int64_t)sizeof(HT)) : nullptr;
         p.P = p0.P ? (int32_t*)((char*)p0.P + pair * p0.hp_pstride * (int64_t)p0.p_bytes) : nullptr;
         if (threadIdx.x < NS) lds.prod_u[threadIdx.x] = 0;
-        if (threadIdx.x < NS * 4) lds.cons_blk[threadIdx.x / 4][threadIdx.x % 4] = ((int)(threadIdx.x % 4) < NC) ? -1 : 0x7fffffff;
+        if (threadIdx.x < NS * 8) lds.cons_blk[threadIdx.x / 8][threadIdx.x % 8] = ((int)(threadIdx.x % 8) < NC) ? -1 : 0x7fffffff;
         if (threadIdx.x == 0) { lds.halo_ready = 1; lds.exp_done = 0; lds.never = 0x7fffffff; }
         const int s0 = grp * NS;
         const int nact = min(NS, p.nstrips - s0);  // active strips of this group
@@ -959,6 +1110,11 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
             role = (wave < NS) ? R_PROD : (wave == h_imp || wave >= NWAVES) ? R_IMP : (wave == h_exp) ? R_EXP : R_CONS;
             cw = wave - NS - (wave > h_imp ? 1 : 0) - (wave > h_exp ? 1 : 0);  // consumer ordinal 0..NS*NC-1
         }
+        if (p.dbg && (p.debug_flags & 64) && blockIdx.x == 0 && lane == 0) {   // where did the hardware put my waves?
+            u32 hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            p.dbg[6 * p.nstrips + 32 + wave] = ((u64)role << 32) | hwid;
+        }
         if (role == R_PROD) {
             // ================================ producer ================================
             const int ls = wave, s = s0 + ls;
@@ -989,8 +1145,8 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                     return lefthalo ? min(u_end, rows + phi + 1) : min(u_end - 1 + hoff, left_total);
                 };
                 auto cons_rows_done = [&]() -> int {
-                    const int a0 = lds_load(&lds.cons_blk[ls][0]), a1 = lds_load(&lds.cons_blk[ls][1]);
-                    const int a2 = lds_load(&lds.cons_blk[ls][2]), a3 = lds_load(&lds.cons_blk[ls][3]);
+                    const int a0 = min(lds_load(&lds.cons_blk[ls][0]), lds_load(&lds.cons_blk[ls][4])), a1 = min(lds_load(&lds.cons_blk[ls][1]), lds_load(&lds.cons_blk[ls][5]));
+                    const int a2 = min(lds_load(&lds.cons_blk[ls][2]), lds_load(&lds.cons_blk[ls][6])), a3 = min(lds_load(&lds.cons_blk[ls][3]), lds_load(&lds.cons_blk[ls][7]));
                     return SY_U * (min(min(a0, a1), min(a2, a3)) + 1);
                 };
 
@@ -1022,7 +1178,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                     int polls[2];
                     const int st = producer_perm(prof_lo, prof_hi, ngap_v, wbase, voff, z1, G0v, G0v + (u32)SW_PERM_PAD, expoff, cb, hbase, hoff * 4, cnt_addr,
                                                  (u32)(size_t)&lds.cons_blk[ls][0], (u32)(size_t)(has_right ? right_cnt : &lds.never),
-                                                 (u32)(size_t)&lds.prod_u[ls], UT, k1, k2, kc, kr, hmask * 4 + 3, erc, polls);
+                                                 (u32)(size_t)&lds.prod_u[ls], UT, k1, k2, kc, kr, hmask * 4 + 3, erc, (p.debug_flags & 32) ? 0 : 64, polls);
                     if (p.dbg && lane == 0) {
                         p.dbg[2 * s + 1] = __builtin_amdgcn_s_memrealtime();
                         p.dbg[4 * p.nstrips + 16 + 2 * s] = (u64)polls[0];
@@ -1130,7 +1286,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
             // ================================ consumer ================================
             const int ls = cw % NS, ci = cw / NS, s = s0 + ls;
             if (ls < nact && (p.debug_flags & 2)) {
-                lds_store(&lds.cons_blk[ls][ci & 3], 1 << 24);  // timing experiment: producer alone
+                lds_store(&lds.cons_blk[ls][ci], 1 << 24);  // timing experiment: producer alone
             } else if (ls < nact) {
                 const int phi = phi_of(s, phib);
                 const u32 j = (u32)s * SY_W + (u32)lane;
@@ -1167,14 +1323,51 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 const u32* myring = (const u32*)&lds.ring[ls][lane * SY_LSTR];
                 int snap_prod = 0;
                 Spin spin;
-                // progress counters: four slots per strip; consumers ci and ci+4 share slot ci%4 (NC > 4)
-                const int slot = ci & 3;
-                const int partner = (NC > 4) ? ((ci >= 4) ? ci - 4 : (ci + 4 < NC ? ci + 4 : -1)) : -1;
+                const int slot = ci;   // progress counters: one slot per consumer
                 // every load issued so far (a, top) has landed before the loop: inside it, a wait for one of them
                 // would be a vmcnt(0), i.e. a wait for all the H/P stores of the previous block as well
                 __builtin_amdgcn_s_waitcnt(0x0F70);
+                // My blocks are ci, ci+NC, ...  The first block of the strip (row 0 comes from the halo row) and the last
+                // one (partial rows, band / tile exports) take the compiler-scheduled path below; everything between runs in
+                // ONE asm statement (consumer_loop32) in the common configuration: int32 H stored, no right-edge output.
+                bool looped = false;
                 for (int q = ci; q < nblk; q += NC) {
-                    const int r0 = q * SY_U + 1;
+                    if constexpr (sizeof(HT) == 4) {
+                        if (!looped && q > 0 && q < nblk - 1 && reread && !right_strip && !(p.debug_flags & (128 | 256))) {
+                            looped = true;
+                            const int qs = __builtin_amdgcn_readfirstlane(q);   // (wave-uniform by construction; say so)
+                            const int nmine = (nblk - 1 - qs + NC - 1) / NC;    // my blocks below the last one
+                            const int qend = qs + nmine * NC;
+                            const int r0 = qs * SY_U + 1;
+                            u32 z = (u32)(cz + ngap * (r0 - 1)), E = (u32)(r0 - 2 + lane + phi);
+                            u32 bv = (u32)bestv, bb = (u32)bestblk;
+                            const uint64_t bH = (uint64_t)(uintptr_t)(H + (int64_t)r0 * M);
+                            const uint64_t bP = (uint64_t)(uintptr_t)(p8 ? (char*)P + (int64_t)r0 * M : (char*)(P + (int64_t)r0 * M));
+                            const sw_i32x4 dH = {(int)(u32)bH, (int)(u32)(bH >> 32), 0x7FFFFF00, 0x00020000};
+                            const sw_i32x4 dP = {(int)(u32)bP, (int)(u32)(bP >> 32), 0x7FFFFF00, 0x00020000};
+                            const u32 rowH = (u32)(M * 4), rowP = (u32)(M * (p8 ? 1 : 4));
+                            const uint64_t blkH = (uint64_t)M * 4u * (uint64_t)(SY_U * NC), blkP = (uint64_t)M * (p8 ? 1u : 4u) * (uint64_t)(SY_U * NC);
+                            const u32 lanebase = (u32)(size_t)&lds.ring[ls][lane * SY_LSTR];
+                            const u32 zstep = (u32)(ngap * SY_U * (NC - 1));
+                            int st;
+#define SW_CLOOP(NTV, P8V)                                                                                                              \
+    st = consumer_loop32<NTV, P8V>(z, E, bv, bb, lanebase, a_lu, mm_v, xm_v, ngap_v, voffP, voffH, zstep, (u32)(SY_U * NC), (u32)(SY_R - 1), dH, \
+                                   dP, blkH, blkP, rowP, rowH, seq_b + (r0 - 1), (u32)(size_t)&lds.prod_u[ls],                            \
+                                   (u32)(size_t)&lds.cons_blk[ls][slot], qs, qend, NC, r0 + SY_U - 1 + SY_W + phi, r0 - 2 + phi)
+                            if (p.store_nt) { if (p8) SW_CLOOP(true, true); else SW_CLOOP(true, false); }
+                            else { if (p8) SW_CLOOP(false, true); else SW_CLOOP(false, false); }
+#undef SW_CLOOP
+                            if (st) {
+                                __hip_atomic_store((gu32*)p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                return;
+                            }
+                            bestv = (int)bv; bestblk = (int)bb;
+                            q = qend - NC;   // the loop's increment lands on my next block
+                            continue;
+                        }
+                    }
+                    const int qu = __builtin_amdgcn_readfirstlane(q);   // wave-uniform by construction; say so (scalar operands below)
+                    const int r0 = qu * SY_U + 1;
                     const int nb = min(SY_U, rows - r0 + 1);
                     const int need = r0 + nb - 1 + SY_W + phi;  // the local step that completes row r0+nb-1
                     if (snap_prod < need)
@@ -1253,7 +1446,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                         }
                     }
                     if (reread) {
-                        if ((int)blkmax > bestv) { bestv = (int)blkmax; bestblk = q; }
+                        if ((int)blkmax > bestv) { bestv = (int)blkmax; bestblk = qu; }
                     } else {
                         const int bm = cell_ok ? (int)blkmax : 0;
                         if (__builtin_amdgcn_ballot_w64(bm > wbest) != 0) {
@@ -1272,8 +1465,8 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                         }
                     }
                     if (p.dbg && (p.debug_flags & 128) && lane == 0)   // per-block completion stamps (after the strip stamps and counters)
-                        p.dbg[6 * p.nstrips + 64 + (int64_t)s * nblk + q] = __builtin_amdgcn_s_memrealtime();
-                    if (p.bot_gran && q == nblk - 1) {
+                        p.dbg[6 * p.nstrips + 64 + (int64_t)s * nblk + qu] = __builtin_amdgcn_s_memrealtime();
+                    if (p.bot_gran && qu == nblk - 1) {
                         // band-resident launch: the band's last row leaves as {tag, H} granules (the next band's halo row)
                         u32 gl = 0;
                         sfor<0, SY_U>([&](auto K) { if (K.value + 1 == nb) gl = gv[K.value + 1]; });
@@ -1286,16 +1479,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                             if (lane == 0) __hip_atomic_store((gu32*)(p.bot_done + s), p.bot_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         }
                     }
-                    if constexpr (NC > 4) {
-                        // a slot shared by two consumers is published in block order: wait for the block before mine
-                        if (partner >= 0) {
-                            const int back = ((q - partner) % NC + NC) % NC;  // 1..NC-1: distance to the partner's latest block below q
-                            const int pred = (q - back >= 0) ? q - back : -1;
-                            while (lds_load(&lds.cons_blk[ls][slot]) != pred)
-                                if (spin.fail(p.abort_flag)) return;
-                        }
-                    }
-                    lds_store(&lds.cons_blk[ls][slot], q);
+                    lds_store(&lds.cons_blk[ls][slot], qu);
                 }
                 // arg-max: the lowest row of block `bestblk` holding bestv in my column (re-read what this wave stored)
                 if (cell_ok && !(p.debug_flags & 1) && bestv > 0) {
