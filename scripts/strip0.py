@@ -17,6 +17,9 @@ def run(cols, rows, flags, ns=1, nc=0, imp=0, pol=0):
     pl = dbg.cpu().numpy()[4 * S + 16: 4 * S + 16 + 2 * S].reshape(S, 2)
     steps = rows + 63 + (S - 1) + 15
     d0 = t[0, 1] - t[0, 0]
+    ck = dbg.cpu().numpy()[6 * S + 48: 6 * S + 50]
+    mhz = (ck[1] - ck[0]) / d0 if d0 > 0 else 0
+    print(f"  strip 0: {(ck[1]-ck[0])/steps:.1f} shader clocks per step at {mhz:.0f} MHz")
     if flags & 64:
         hw = dbg.cpu().numpy()[6 * S + 32: 6 * S + 32 + 16]
         print("  wave: role simd (HW_ID bits 5:4), cu, wave_id:", [(i, int(h >> 32), int((h >> 4) & 3), int((h >> 8) & 15), int(h & 15)) for i, h in enumerate(hw) if h])

@@ -112,6 +112,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "importers")) { if (v < 0 || v > 8) return SW_EINVAL; c->opt_importers = v ? v : 2; return SW_OK; }
     if (!strcmp(name, "debug_buf")) { c->opt_dbg_ptr = v; return SW_OK; }
     if (!strcmp(name, "band_wait_ms")) { c->opt_band_wait_ms = v > 0 ? v : 20000; return SW_OK; }
+    if (!strcmp(name, "debug_epoch8")) { c->epoch8 = (unsigned)(v & 255); return SW_OK; }   // development aid: next launch tag = v + 1
     if (!strcmp(name, "engine")) {
         if (v != 0 && v != 1) { set_err("engine must be 0 (systolic) or 1 (strip_scan)"); return SW_EINVAL; }
         c->opt_engine = v;
@@ -134,6 +135,8 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "pace_ps")) return c->opt_pace_ps;
     if (!strcmp(name, "band_wait_ms")) return c->opt_band_wait_ms;
     if (!strcmp(name, "num_cus")) return c->num_cus;
+    if (!strcmp(name, "debug_edge4_ptr")) return (int64_t)(uintptr_t)c->d_edge4;
+    if (!strcmp(name, "debug_edge4_cap")) return (int64_t)c->edge4_cap;
     if (!strcmp(name, "last_grid")) return c->last_grid;
     if (!strcmp(name, "last_strips")) return c->last_strips;
     return -1;
@@ -278,7 +281,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         const bool perm_ok = !halo_unbounded && p.mm <= 127 && p.mm >= -127 && p.xm <= 127 && p.xm >= -127 && gmax + 0x10000 + 1024 < (1ll << 24) &&
                              !(c->opt_debug & 16);
         if (perm_ok) {
-            const int64_t e4stride = ((rows + S + 96 + 3) / 4) * 4;
+            const int64_t e4stride = ((rows + S + 160 + 3) / 4) * 4;
             const size_t need4 = (size_t)S * (size_t)e4stride * (size_t)j.npairs;
             if (need4 > c->edge4_cap) {
                 HIP_TRY(hipStreamSynchronize(stream));
@@ -286,11 +289,11 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 c->d_edge4 = nullptr; c->edge4_cap = 0;
                 if (hipMalloc((void**)&c->d_edge4, need4 * 4) != hipSuccess) { set_err("workspace allocation of %zu bytes failed", need4 * 4); return SW_ENOMEM; }
                 c->edge4_cap = need4;
-                HIP_TRY(hipMemsetAsync(c->d_edge4, 0, need4 * 4, stream));
-                c->epoch8 = 0;
+                c->epoch8 = 255;   // fresh memory: wipe it below
             }
-            if (++c->epoch8 >= 256) {   // 8-bit tag wrapped: wipe stale values
-                HIP_TRY(hipMemsetAsync(c->d_edge4, 0, c->edge4_cap * 4, stream));
+            if (++c->epoch8 >= (unsigned)((c->opt_debug & 1024) ? 4 : 256)) {   // 8-bit tag wrapped: wipe stale values (debug bit 10: wrap early)
+                const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((c->edge4_cap + 255) / 256, 2048));
+                hipLaunchKernelGGL(swk::sw_wipe_u32, dim3(nb), dim3(256), 0, stream, c->d_edge4, c->edge4_cap);
                 c->epoch8 = 1;
             }
             p.edge4 = c->d_edge4; p.e4stride = e4stride; p.edge4_pstride = (int64_t)S * e4stride;

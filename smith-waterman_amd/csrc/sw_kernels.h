@@ -58,6 +58,7 @@ template <typename HT, int B>
 __global__ void sw_strip_scan(const unsigned char* a, const unsigned char* b, FillParams p);
 template <typename HT, int NS, int NC>
 __global__ void sw_systolic(const unsigned char* a, const unsigned char* b, const unsigned char* bpad, FillParams p);
+__global__ void sw_wipe_u32(unsigned int* buf, size_t n);
 __global__ void sw_alpha_scan(const unsigned char* a, int64_t cols, int64_t a_pstride, const unsigned char* b, int64_t rows, int64_t b_pstride,
                               int64_t npairs, unsigned int* present);
 __global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, int64_t b_pstride, unsigned char* bpad, unsigned short* bpad16,

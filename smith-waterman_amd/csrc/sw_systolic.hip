@@ -437,26 +437,44 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
     "v_add_u32 v121, v121, %[ngap]\n\t"                                                           \
     "v_add_u32_sdwa " TP1 ", " GP ", sext(" SREG ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BYTE "\n\t" \
     "v_max_i32_dpp " GK ", v120, " GP " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-#define PP_G0(SP3, S0)                                                                            \
-    PP_STEP("v100", "v115", "v118", "v119", SP3, "BYTE_3") PP_STEP("v101", "v100", "v119", "v116", S0, "BYTE_0")   \
-    PP_STEP("v102", "v101", "v116", "v117", S0, "BYTE_1") PP_STEP("v103", "v102", "v117", "v118", S0, "BYTE_2")
-#define PP_G1(S0, S1)                                                                             \
-    PP_STEP("v104", "v103", "v118", "v119", S0, "BYTE_3") PP_STEP("v105", "v104", "v119", "v116", S1, "BYTE_0")   \
-    PP_STEP("v106", "v105", "v116", "v117", S1, "BYTE_1") PP_STEP("v107", "v106", "v117", "v118", S1, "BYTE_2")
-#define PP_G2(S1, S2)                                                                             \
-    PP_STEP("v108", "v107", "v118", "v119", S1, "BYTE_3") PP_STEP("v109", "v108", "v119", "v116", S2, "BYTE_0")   \
-    PP_STEP("v110", "v109", "v116", "v117", S2, "BYTE_1") PP_STEP("v111", "v110", "v117", "v118", S2, "BYTE_2")
-#define PP_G3(S2, S3)                                                                             \
-    PP_STEP("v112", "v111", "v118", "v119", S2, "BYTE_3") PP_STEP("v113", "v112", "v119", "v116", S3, "BYTE_0")   \
-    PP_STEP("v114", "v113", "v116", "v117", S3, "BYTE_1") PP_STEP("v115", "v114", "v117", "v118", S3, "BYTE_2")
+// a group = 4 steps; xA is its first step (after which the registers of the group before it are dead), xB the other three
+#define PP_G0A(SP3) PP_STEP("v100", "v115", "v118", "v119", SP3, "BYTE_3")
+#define PP_G0B(S0) PP_STEP("v101", "v100", "v119", "v116", S0, "BYTE_0") PP_STEP("v102", "v101", "v116", "v117", S0, "BYTE_1") PP_STEP("v103", "v102", "v117", "v118", S0, "BYTE_2")
+#define PP_G1A(S0) PP_STEP("v104", "v103", "v118", "v119", S0, "BYTE_3")
+#define PP_G1B(S1) PP_STEP("v105", "v104", "v119", "v116", S1, "BYTE_0") PP_STEP("v106", "v105", "v116", "v117", S1, "BYTE_1") PP_STEP("v107", "v106", "v117", "v118", S1, "BYTE_2")
+#define PP_G2A(S1) PP_STEP("v108", "v107", "v118", "v119", S1, "BYTE_3")
+#define PP_G2B(S2) PP_STEP("v109", "v108", "v119", "v116", S2, "BYTE_0") PP_STEP("v110", "v109", "v116", "v117", S2, "BYTE_1") PP_STEP("v111", "v110", "v117", "v118", S2, "BYTE_2")
+#define PP_G3A(S2) PP_STEP("v112", "v111", "v118", "v119", S2, "BYTE_3")
+#define PP_G3B(S3) PP_STEP("v113", "v112", "v119", "v116", S3, "BYTE_0") PP_STEP("v114", "v113", "v116", "v117", S3, "BYTE_1") PP_STEP("v115", "v114", "v117", "v118", S3, "BYTE_2")
+#ifdef PP_NO_EXPORT   /* tools/ubench_prod.hip: what does each part of the block cost? */
+#define PP_KX(X) ""
+#else
+#define PP_KX(X) X
+#endif
 // One 16-step block.  KB: first step's index in the chunk.  SP3: score dword holding the step before the block;
 // S0..S3 / C0..C3: this block's score and code dwords; NB, PF: code buffer that receives the block three ahead and its
-// byte offset; HN0, HN1: operands of the next block's first two halo groups; L0/L1/LE: lgkmcnt of the waits for halo
-// group 0 / group 1 / the left counter (they differ where back-pressure fetches sit in the LDS queue); BPF: those fetches.
-// LDS order: [G0] W0 R2 [G1] W1 R3 [G2] W2 Rc R0' [G3] W3 R1' (BPF) | evaluate Rc | Wp
-#define PP_BLOCK(KB, SP3, S0, S1, S2, S3, C0, C1, C2, C3, NB, PF, O0, O1, O2, O3, H2, H3, HN0, HN1, L0, L1, LE, BPF)  \
-    "s_cmp_eq_u32 s84, 0\n\t"                                                                \
-    "s_cbranch_scc1 Lslow" #KB "_%=\n"                                                       \
+// byte offset; O0..O3: ring / export byte offsets of the four groups; H3: halo offset of this block's last group; HN0..HN2:
+// operands of the NEXT block's first three halo groups; LA, LB: lgkmcnt of the two waits (they differ where back-pressure
+// fetches sit in the LDS queue); BPF: those fetches.
+// Every halo group is fetched 11 steps before its first use, right after the step that last read its registers, so no
+// wait ever stalls (measured: fetching 4-5 steps ahead cost ~20 clk per wait, 5 clk per step).  The left neighbour's
+// progress is sampled (Rc) BEFORE the next block's groups are fetched and evaluated at the next block's start: if it
+// covered that whole block then, what was fetched is valid; else the slow path polls and fetches again.
+// LDS order: [k0] R3 [k1-3] W0 [k4] Rc R0' [k5-7] W1 [k8] R1' [k9-11] W2 (BPF) [k12] R2' [k13-15] W3 Wp
+#ifdef PP_LATE_R   /* experiment: fetch the halo groups three steps later */
+#define PP_RA(X) ""
+#define PP_RB(X) X
+#else
+#define PP_RA(X) X
+#define PP_RB(X) ""
+#endif
+#define PP_BLOCK(KB, SP3, S0, S1, S2, S3, C0, C1, C2, C3, NB, PF, O0, O1, O2, O3, H3, HN0, HN1, HN2, LA, LB, BPF)  \
+    "s_waitcnt lgkmcnt(" LA ")\n\t"                   /* Rc and this block's groups 0, 1 */     \
+    "v_readfirstlane_b32 s85, v86\n\t"                                                       \
+    "s_add_i32 s83, s83, 16\n\t"                                                             \
+    "s_min_i32 s86, s83, %[k2]\n\t"                                                          \
+    "s_cmp_ge_i32 s85, s86\n\t"                                                              \
+    "s_cbranch_scc0 Lslow" #KB "_%=\n"                                                       \
     "Lgo" #KB "_%=:\n\t"                                                                     \
     "s_waitcnt vmcnt(14)\n\t"                                                                \
     "global_load_dwordx4 " NB ", v96, s[92:93] offset:" PF "\n\t"                            \
@@ -464,44 +482,39 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
     "v_perm_b32 " S1 ", %[phi], %[plo], " C1 "\n\t"                                          \
     "v_perm_b32 " S2 ", %[phi], %[plo], " C2 "\n\t"                                          \
     "v_perm_b32 " S3 ", %[phi], %[plo], " C3 "\n\t"                                          \
-    "s_waitcnt lgkmcnt(" L0 ")\n\t"                                                          \
-    PP_G0(SP3, S0)                                                                           \
+    PP_G0A(SP3)                                                                              \
+    PP_RA("ds_read_b128 v[112:115], v98 offset:" H3 "\n\t")                                  \
+    PP_G0B(S0)                                                                               \
+    PP_RB("ds_read_b128 v[112:115], v98 offset:" H3 "\n\t")                                  \
     "ds_write_b128 v126, v[100:103] offset:" O0 "\n\t"                                       \
-    "buffer_store_dwordx4 v[100:103], v97, s[76:79], s75 offen offset:" O0 " sc1\n\t"        \
-    "ds_read_b128 v[108:111], v98 offset:" H2 "\n\t"                                         \
-    "s_waitcnt lgkmcnt(" L1 ")\n\t"                                                          \
-    PP_G1(S0, S1)                                                                            \
-    "ds_write_b128 v126, v[104:107] offset:" O1 "\n\t"                                       \
-    "buffer_store_dwordx4 v[104:107], v97, s[76:79], s75 offen offset:" O1 " sc1\n\t"        \
-    "ds_read_b128 v[112:115], v98 offset:" H3 "\n\t"                                         \
-    "s_waitcnt lgkmcnt(2)\n\t"                                                               \
-    PP_G2(S1, S2)                                                                            \
-    "ds_write_b128 v126, v[108:111] offset:" O2 "\n\t"                                       \
-    "buffer_store_dwordx4 v[108:111], v97, s[76:79], s75 offen offset:" O2 " sc1\n\t"        \
-    /* the left neighbour's progress, THEN (in LDS order behind it) the next block's first two halo groups */  \
+    PP_KX("buffer_store_dwordx4 v[100:103], v97, s[76:79], s75 offen offset:" O0 " sc1\n\t") \
+    PP_G1A(S0)                                                                               \
     "ds_read_b32 v86, v88\n\t"                                                               \
-    "ds_read_b128 v[100:103], " HN0 "\n\t"                                                   \
-    "s_waitcnt lgkmcnt(3)\n\t"                                                               \
-    PP_G3(S2, S3)                                                                            \
-    "ds_write_b128 v126, v[112:115] offset:" O3 "\n\t"                                       \
-    "buffer_store_dwordx4 v[112:115], v97, s[76:79], s75 offen offset:" O3 " sc1\n\t"        \
-    "ds_read_b128 v[104:107], " HN1 "\n\t"                                                   \
+    PP_RA("ds_read_b128 v[100:103], " HN0 "\n\t")                                            \
+    PP_G1B(S1)                                                                               \
+    PP_RB("ds_read_b128 v[100:103], " HN0 "\n\t")                                            \
+    "ds_write_b128 v126, v[104:107] offset:" O1 "\n\t"                                       \
+    PP_KX("buffer_store_dwordx4 v[104:107], v97, s[76:79], s75 offen offset:" O1 " sc1\n\t") \
+    "s_waitcnt lgkmcnt(" LB ")\n\t"                   /* this block's groups 2, 3 */            \
+    PP_G2A(S1)                                                                               \
+    PP_RA("ds_read_b128 v[104:107], " HN1 "\n\t")                                            \
+    PP_G2B(S2)                                                                               \
+    PP_RB("ds_read_b128 v[104:107], " HN1 "\n\t")                                            \
+    "ds_write_b128 v126, v[108:111] offset:" O2 "\n\t"                                       \
+    PP_KX("buffer_store_dwordx4 v[108:111], v97, s[76:79], s75 offen offset:" O2 " sc1\n\t") \
     BPF                                                                                      \
-    "s_waitcnt lgkmcnt(" LE ")\n\t"                                                          \
-    "v_readfirstlane_b32 s85, v86\n\t"                                                       \
-    "s_add_i32 s86, s88, %[k1]\n\t"                                                          \
-    "s_min_i32 s86, s86, %[k2]\n\t"                                                          \
-    "s_cmp_ge_i32 s85, s86\n\t"                                                              \
-    "s_cselect_b32 s84, 1, 0\n\t"                                                            \
-    "s_add_i32 s87, s88, 15\n\t"                                                             \
-    "v_mov_b32 v87, s87\n\t"                                                                 \
-    "ds_write_b32 v91, v87\n\t"                                                              \
-    "s_add_i32 s88, s88, 16\n\t"                                                             \
-    "s_cmp_gt_i32 s88, %[ut]\n\t"                                                            \
-    "s_cbranch_scc1 Lexit_%=\n\t"
+    PP_G3A(S2)                                                                               \
+    PP_RA("ds_read_b128 v[108:111], " HN2 "\n\t")                                            \
+    PP_G3B(S3)                                                                               \
+    PP_RB("ds_read_b128 v[108:111], " HN2 "\n\t")                                            \
+    "ds_write_b128 v126, v[112:115] offset:" O3 "\n\t"                                       \
+    PP_KX("buffer_store_dwordx4 v[112:115], v97, s[76:79], s75 offen offset:" O3 " sc1\n\t") \
+    "v_add_u32 v87, 16, v87\n\t"                                                             \
+    "ds_write_b32 v91, v87\n\t"
 #define PP_BPFETCH "ds_read_b128 v[80:83], v89\n\tds_read_b128 v[52:55], v89 offset:16\n\tds_read_b32 v84, v90\n\t"
-#define PP_BPCHECK(T)                                                                         \
-    "s_waitcnt lgkmcnt(1)\n\t"                                                               \
+// ring back-pressure before the 32 steps that start at local step s88 + D (D = 0 / 32: operands kc/kr, kc32/kr32)
+#define PP_BPCHECK(T, KC, KR)                                                                 \
+    "s_waitcnt lgkmcnt(3)\n\t"                        /* the fetches sit in front of R2', W3, Wp */ \
     "v_min3_i32 v92, v80, v81, v82\n\t"                                                      \
     "v_min3_i32 v93, v83, v52, v53\n\t"                                                      \
     "v_min3_i32 v92, v92, v54, v55\n\t"                                                      \
@@ -512,10 +525,10 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
     "Lbpe" T "_%=:\n\t"                                                                      \
     "s_lshl_b32 s85, s85, 4\n\t"                                                             \
     "s_add_i32 s85, s85, 16\n\t"                                                             \
-    "s_add_i32 s87, s88, %[kc]\n\t"                                                          \
+    "s_add_i32 s87, s88, " KC "\n\t"                                                         \
     "s_cmp_ge_i32 s85, s87\n\t"                                                              \
     "s_cbranch_scc0 Lbpw" T "_%=\n\t"                                                        \
-    "s_add_i32 s87, s88, %[kr]\n\t"                                                          \
+    "s_add_i32 s87, s88, " KR "\n\t"                                                         \
     "s_cmp_ge_i32 s86, s87\n\t"                                                              \
     "s_cbranch_scc1 Lbpok" T "_%=\n"                                                         \
     "Lbpw" T "_%=:\n\t"                                                                      \
@@ -537,17 +550,15 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
     "v_readfirstlane_b32 s86, v84\n\t"                                                       \
     "s_branch Lbpe" T "_%=\n"                                                                \
     "Lbpok" T "_%=:\n\t"
-// out-of-line: wait until the left neighbour has produced this block's halo, then fetch its first two groups
-#define PP_SLOW(KB, R0, R1)                                                                   \
+// out-of-line: wait until the left neighbour has produced this block's halo, then fetch its first three groups
+#define PP_SLOW(KB, R0, R1, R2)                                                               \
     "Lslow" #KB "_%=:\n\t"                                                                   \
     "s_mov_b32 s89, 0\n"                                                                     \
     "Lpoll" #KB "_%=:\n\t"                                                                   \
     "ds_read_b32 v86, v88\n\t"                                                               \
     "s_waitcnt lgkmcnt(0)\n\t"                                                               \
     "v_readfirstlane_b32 s85, v86\n\t"                                                       \
-    "s_add_i32 s86, s88, %[k1]\n\t"                                                          \
-    "s_add_i32 s86, s86, -16\n\t"                                                            \
-    "s_min_i32 s86, s86, %[k2]\n\t"                                                          \
+    "s_nop 3\n\t"                                                                            \
     "s_cmp_ge_i32 s85, s86\n\t"                                                              \
     "s_cbranch_scc1 Lrd" #KB "_%=\n\t"                                                       \
     "s_sleep 1\n\t"                                                                          \
@@ -560,19 +571,23 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
     "Lrd" #KB "_%=:\n\t"                                                                     \
     "ds_read_b128 v[100:103], v98 offset:" R0 "\n\t"                                         \
     "ds_read_b128 v[104:107], v98 offset:" R1 "\n\t"                                         \
+    "ds_read_b128 v[108:111], v98 offset:" R2 "\n\t"                                         \
     "s_waitcnt lgkmcnt(0)\n\t"                                                               \
     "s_branch Lgo" #KB "_%=\n"
 
 typedef int sw_i32x4p __attribute__((ext_vector_type(4)));
+// UT must be a multiple of 64 (the exit test sits at the end of a chunk)
 __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 wbase, u32 voff, u32 z1, u32 g0, u32 tm1, u32 expoff,
                                              const unsigned char* cbase, u32 hbase, int hoff4, u32 cnt_addr, u32 cons_addr,
                                              u32 right_addr, u32 prog_addr, int UT, int k1, int k2, int kc, int kr, int hmask,
                                              sw_i32x4p erc, int cinc, int (&polls)[2]) {
     int status;
+    const int need0 = 1 + k1 - 32;    // + 16 per block: the left progress that makes a whole block's halo readable
+    const int kc32 = kc + 32, kr32 = kr + 32;
     asm volatile(
         "s_setprio 3\n\t"
         "s_mov_b32 %[status], 0\n\t"
-        "s_mov_b32 s84, 0\n\t"
+        "s_mov_b32 s83, %[need0]\n\t"
         "s_mov_b32 s94, 0\n\t"
         "s_mov_b32 s95, 0\n\t"
         "s_mov_b32 s88, 1\n\t"
@@ -593,6 +608,8 @@ __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 w
         "v_mov_b32 v115, %[g0]\n\t"               /* step 0: every lane holds its row-0 value */
         "v_mov_b32 v118, %[tm1]\n\t"              /* t of step -1 */
         "v_mov_b32 v121, %[z1]\n\t"               /* floor of step 1 */
+        "v_mov_b32 v86, 0\n\t"                    /* left progress as last sampled: nothing yet -> the first block takes the slow path */
+        "v_mov_b32 v87, 0\n\t"                    /* my progress (completed local steps) */
         "v_mov_b32 v80, 0\n\t"
         "v_mov_b32 v81, 0\n\t"
         "v_mov_b32 v82, 0\n\t"
@@ -612,7 +629,7 @@ __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 w
         "s_waitcnt vmcnt(0)\n\t"
         "v_perm_b32 v63, %[phi], %[plo], v79\n"
         "Lchunk_%=:\n\t"
-        PP_BPCHECK("A")
+        PP_BPCHECK("A", "%[kc]", "%[kr]")
         "v_add_u32 v126, s90, %[wbase]\n\t"
         "v_mov_b32 v98, %[hbase]\n\t"
         "v_add_u32 v98, s91, v98\n\t"
@@ -621,21 +638,24 @@ __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 w
         "v_mov_b32 v99, %[hbase]\n\t"
         "v_add_u32 v99, s91, v99\n\t"
         PP_BLOCK(0, "v63", "v122", "v123", "v124", "v125", "v64", "v65", "v66", "v67", "v[76:79]", "0", "0", "16", "32", "48",
-                 "32", "48", "v98 offset:64", "v98 offset:80", "3", "3", "3", "")
+                 "48", "v98 offset:64", "v98 offset:80", "v98 offset:96", "4", "4", "")
         PP_BLOCK(16, "v125", "v60", "v61", "v62", "v63", "v68", "v69", "v70", "v71", "v[64:67]", "16", "64", "80", "96", "112",
-                 "96", "112", "v98 offset:128", "v98 offset:144", "3", "3", "6", PP_BPFETCH)
-        PP_BPCHECK("B")
+                 "112", "v98 offset:128", "v98 offset:144", "v98 offset:160", "4", "4", PP_BPFETCH)
+        PP_BPCHECK("B", "%[kc32]", "%[kr32]")
         PP_BLOCK(32, "v63", "v122", "v123", "v124", "v125", "v72", "v73", "v74", "v75", "v[68:71]", "32", "128", "144", "160", "176",
-                 "160", "176", "v98 offset:192", "v98 offset:208", "3", "3", "3", "")
+                 "176", "v98 offset:192", "v98 offset:208", "v98 offset:224", "4", "4", "")
         PP_BLOCK(48, "v125", "v60", "v61", "v62", "v63", "v76", "v77", "v78", "v79", "v[72:75]", "48", "192", "208", "224", "240",
-                 "224", "240", "v99", "v99 offset:16", "3", "3", "6", PP_BPFETCH)
+                 "240", "v99", "v99 offset:16", "v99 offset:32", "4", "4", PP_BPFETCH)
         "s_add_i32 s90, s90, 256\n\t"
         "s_and_b32 s90, s90, 1023\n\t"
         "s_add_i32 s75, s75, 256\n\t"
         "s_add_u32 s92, s92, %[cinc]\n\t"
         "s_addc_u32 s93, s93, 0\n\t"
-        "s_branch Lchunk_%=\n"
-        PP_SLOW(0, "0", "16") PP_SLOW(16, "64", "80") PP_SLOW(32, "128", "144") PP_SLOW(48, "192", "208")
+        "s_add_i32 s88, s88, 64\n\t"
+        "s_cmp_gt_i32 s88, %[ut]\n\t"
+        "s_cbranch_scc0 Lchunk_%=\n\t"
+        "s_branch Lexit_%=\n"
+        PP_SLOW(0, "0", "16", "32") PP_SLOW(16, "64", "80", "96") PP_SLOW(32, "128", "144", "160") PP_SLOW(48, "192", "208", "224")
         "Lbpfail_%=:\n\t"
         "s_mov_b32 %[status], 2\n"
         "Lexit_%=:\n\t"
@@ -646,9 +666,9 @@ __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 w
         : [status] "=&s"(status), [nbp] "=&s"(polls[0]), [nhalo] "=&s"(polls[1])
         : [plo] "v"(plo), [phi] "v"(phi), [ngap] "v"(ngap_v), [wbase] "v"(wbase), [voff] "v"(voff), [z1] "v"(z1), [g0] "v"(g0), [tm1] "v"(tm1),
           [expoff] "v"(expoff), [cbase] "s"(cbase), [hbase] "s"(hbase), [hoff4] "s"(hoff4), [cntaddr] "s"(cnt_addr), [consaddr] "s"(cons_addr),
-          [rightaddr] "s"(right_addr), [progaddr] "s"(prog_addr), [ut] "s"(UT), [k1] "s"(k1), [k2] "s"(k2), [kc] "s"(kc), [kr] "s"(kr),
-          [hmask] "s"(hmask), [e0] "s"(erc.x), [e1] "s"(erc.y), [e2] "s"(erc.z), [e3] "s"(erc.w), [cinc] "s"(cinc)
-        : "vcc", "scc", "memory", "s75", "s76", "s77", "s78", "s79", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
+          [rightaddr] "s"(right_addr), [progaddr] "s"(prog_addr), [ut] "s"(UT), [need0] "s"(need0), [k2] "s"(k2), [kc] "s"(kc), [kr] "s"(kr),
+          [kc32] "s"(kc32), [kr32] "s"(kr32), [hmask] "s"(hmask), [e0] "s"(erc.x), [e1] "s"(erc.y), [e2] "s"(erc.z), [e3] "s"(erc.w), [cinc] "s"(cinc)
+        : "vcc", "scc", "memory", "s75", "s76", "s77", "s78", "s79", "s83", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
           "s95", "v52", "v53", "v54", "v55", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
           "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v96", "v97", "v98", "v99", "v100",
           "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
@@ -1022,7 +1042,8 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
     const bool perm = (p.gbias != 0) && (*(const unsigned int*)(p.atab + 256) <= 7u) && !(p.debug_flags & 16);
     const int phib = perm ? p.nstrips - 1 : p.phi_base;
     const int gb = perm ? (int)p.gbias : 0;       // carried by every G value
-    auto u_total = [&](int s) { return (rows + SY_W + phi_of(s, phib) + SY_U - 1) / SY_U * SY_U; };  // local steps 1..u_total
+    const int ugran = perm ? 64 : SY_U;   // the perm producer tests for the end once per 64-step chunk
+    auto u_total = [&](int s) { return (rows + SY_W + phi_of(s, phib) + ugran - 1) / ugran * ugran; };  // local steps 1..u_total
 
     const unsigned char* const seq_a0 = seq_a; const unsigned char* const seq_b0 = seq_b; const unsigned char* const bpad0 = bpad;
     const FillParams p0 = p;
@@ -1057,6 +1078,8 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
         if (threadIdx.x < NS) lds.prod_u[threadIdx.x] = 0;
         if (threadIdx.x < NS * 8) lds.cons_blk[threadIdx.x / 8][threadIdx.x % 8] = ((int)(threadIdx.x % 8) < NC) ? -1 : 0x7fffffff;
         if (threadIdx.x == 0) { lds.halo_ready = 1; lds.exp_done = 0; lds.never = 0x7fffffff; }
+        if (p.debug_flags & 2048)   // poison the halo ring: any slot consumed before an importer wrote it shows up in the output
+            for (int i = threadIdx.x; i < SY_RH; i += blockDim.x) lds.halo[i] = p.gbias + 0x700000u + (u32)i;
         const int s0 = grp * NS;
         const int nact = min(NS, p.nstrips - s0);  // active strips of this group
         const bool has_top = (p.top != nullptr) || (p.top_gran != nullptr);
@@ -1151,6 +1174,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 };
 
                 if (p.dbg && lane == 0) p.dbg[2 * s] = __builtin_amdgcn_s_memrealtime();
+                if (p.dbg && lane == 0 && s == 0) p.dbg[6 * p.nstrips + 48] = __builtin_amdgcn_s_memtime();   // shader clocks too: what does the chip run at?
                 if (perm) {
                     // ---- perm producer (whole strip loop in one asm statement) ----
                     // profile of this lane: score of its NEXT column's letter against every letter code (7: outside)
@@ -1169,7 +1193,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                     const u32 voff = 63u - (u32)lane;
                     const u32 z1 = (u32)(gb + ngap * (1 - phi + s * SY_W));       // floor of local step 1
                     const int k1 = lefthalo ? 2 * SY_U : 2 * SY_U - 1 + hoff;
-                    const int k2 = lefthalo ? rows + phi + 1 : left_total;
+                    const int k2 = lefthalo ? 0x7fffff00 : left_total;   // the importer defines the halo of every step, below the matrix too
                     const int kc = 30 - SY_R - phi;
                     const int kr = (has_right ? -(SY_R + 1) + 16 : -SY_R - phi) - 32;
                     const u32 expoff = (has_export && lane == 63) ? 0u : SY_OOB;
@@ -1181,6 +1205,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                                                  (u32)(size_t)&lds.prod_u[ls], UT, k1, k2, kc, kr, hmask * 4 + 3, erc, (p.debug_flags & 32) ? 0 : 64, polls);
                     if (p.dbg && lane == 0) {
                         p.dbg[2 * s + 1] = __builtin_amdgcn_s_memrealtime();
+                        if (s == 0) p.dbg[6 * p.nstrips + 49] = __builtin_amdgcn_s_memtime();
                         p.dbg[4 * p.nstrips + 16 + 2 * s] = (u64)polls[0];
                         p.dbg[4 * p.nstrips + 17 + 2 * s] = (u64)polls[1];
                     }
@@ -1506,11 +1531,16 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 // ---- perm path: the left group's last producer stored its lane-63 results itself, as 4-byte values that
                 // carry the launch tag, indexed by ITS local step; my strip's local step u needs its step u + 64.
                 // There is no exporter.  Steps above the matrix (rows <= 0) hold the row-0 value of the halo column.
-                const bool importer_w = (role == R_IMP || role == R_EXP);   // nothing to export here: one more importer
+                // (debug bit 12: a single importer wave)
+                const bool importer_w = (p.debug_flags & 4096) ? (role == R_EXP) : (role == R_IMP || role == R_EXP);   // nothing to export here: one more importer
                 if (importer_w) {
                     const int phi0 = phi_of(s0, phib);
                     const u32 row0v = (u32)(gb + top_at(0, 0, (int64_t)s0 * SY_W) + ngap * s0 * SY_W);
-                    const int ulast = rows + phi0;                 // last local step whose halo is a matrix row
+                    // Steps whose halo row lies BELOW the matrix (the other lanes are still inside it) get the launch bias, a
+                    // value below every floor: the producer must never meet left-over LDS contents there.  Round 2 found what
+                    // happens otherwise: such garbage rode through the (unused) cells below the matrix into the exported
+                    // values, grew past 24 bits, and with the tag byte bumped by one was accepted by the NEXT launch.
+                    const int ulast = u_total(s0) + 64;            // every local step the producer may fetch a halo for
                     const u32 tag = (u32)gb >> 24;
                     const u32* e4 = (s0 > 0) ? p.edge4 + (int64_t)(s0 - 1) * p.e4stride : nullptr;
                     int impu = 1;
@@ -1532,10 +1562,11 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                                 const int r = u - phi0;
                                 u32 v = row0v;
                                 bool ok = true;
-                                if (r > 0) {
-                                    if (s0 == 0) v = (u32)(gb + ngap * r + (p.left ? p.left[min(r, rows)] : 0));
+                                if (r > rows) v = (u32)gb;
+                                else if (r > 0) {
+                                    if (s0 == 0) v = (u32)(gb + ngap * r + (p.left ? p.left[r] : 0));
                                     else {
-                                        v = __hip_atomic_load((gu32*)(e4 + min(u, ulast) + 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        v = __hip_atomic_load((gu32*)(e4 + u + 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                         ok = (v >> 24) == tag;
                                     }
                                 }
@@ -1549,8 +1580,10 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                                 const u64 okm = __ballot(oks[b4]);
                                 const int npre = (okm == ~0ull) ? 64 : __builtin_ctzll(~okm);
                                 if (base == impu + b4 * 64 && npre > 0) {
-                                    if (lane < npre && (front2 <= 1 || u >= front2))
+                                    if (lane < npre && (front2 <= 1 || u >= front2)) {
                                         __hip_atomic_store(&lds.halo[(u - 1) & (SY_RH - 1)], vals[b4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        if (p.dbg && (p.debug_flags & 512) && u < 256) p.dbg[1024 + (int64_t)s0 * 1024 + u] = ((u64)(u32)wave << 32) | vals[b4];
+                                    }
                                     base += npre;
                                 }
                             }
@@ -1691,6 +1724,11 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
             }
         }
         __syncthreads();
+        if (p.dbg && (p.debug_flags & 512) && threadIdx.x < 256) {
+            const u32* r0 = (const u32*)&lds.ring[0][0];
+            p.dbg[1024 + (int64_t)s0 * 1024 + 256 + threadIdx.x] = r0[threadIdx.x];          // lane 0, steps 1..256 (ring slot = step-1)
+            p.dbg[1024 + (int64_t)s0 * 1024 + 512 + threadIdx.x] = lds.halo[threadIdx.x];    // the halo ring itself
+        }
     }
 }
 
@@ -1706,6 +1744,15 @@ SW_INST(1, 4)
 SW_INST(1, 6)
 SW_INST(1, 7)
 #undef SW_INST
+
+// Wipe the self-tagged edge buffer with the SAME kind of store the producers use (agent-scope, written through): the
+// importers read it with agent-scope loads that are served from memory, and a plain memset's zeros can still sit in the
+// writing XCD's L2 at that time -- stale words of an earlier owner of the memory whose top byte happens to equal the
+// launch tag were then taken for data (seen as one wrong fill in ~200 around tags 0x38..0x40, the top bytes of floats).
+__global__ void __launch_bounds__(256) sw_wipe_u32(unsigned int* __restrict__ buf, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        __hip_atomic_store((gu32*)(buf + i), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Which byte values occur in a and b (all pairs of a batch): 256-bit presence map, OR-ed into present[8].
 __global__ void __launch_bounds__(256) sw_alpha_scan(const unsigned char* __restrict__ a, int64_t cols, int64_t a_pstride,

@@ -23,7 +23,11 @@ def check_against_oracle(engine, oracle, a, b, scores=(3, -3, -2), h_dtype=None)
     out = engine.fill(a, b, scores, h_dtype=h_dtype)
     H, P, mp = oracle.fill(a, b, scores)
     dH = out.H.cpu().numpy()
-    assert np.array_equal(dH.astype(np.int64), H.astype(np.int64)), "H differs"
+    if not np.array_equal(dH.astype(np.int64), H.astype(np.int64)):
+        bad = np.argwhere(dH.astype(np.int64) != H.astype(np.int64))
+        r, c = bad[0]
+        raise AssertionError(f"H differs in {len(bad)} cells, first at row {r} col {c} (strip {(c - 1) // 63}); rows {bad[:, 0].min()}..{bad[:, 0].max()}, "
+                             f"cols {bad[:, 1].min()}..{bad[:, 1].max()}; got {dH[r, max(0, c - 2):c + 3].tolist()} want {H[r, max(0, c - 2):c + 3].tolist()}")
     assert np.array_equal(out.P.cpu().numpy(), P), "P differs"
     r = out.result()
     assert r["max_pos"] == mp and r["max_score"] == int(H.flat[mp])
@@ -37,8 +41,12 @@ def check_against_oracle(engine, oracle, a, b, scores=(3, -3, -2), h_dtype=None)
 def test_golden_fixtures(engine, name):
     g = golden(name)
     out = engine.fill(g["a"], g["b"])
-    assert np.array_equal(out.H.cpu().numpy(), g["H"])
-    assert np.array_equal(out.P.cpu().numpy(), g["P0"])
+    for what, got, want in (("H", out.H.cpu().numpy(), g["H"]), ("P", out.P.cpu().numpy(), g["P0"])):
+        if not np.array_equal(got, want):
+            bad = np.argwhere(got != want)
+            r, c = bad[0]
+            raise AssertionError(f"{what} differs in {len(bad)} cells: rows {bad[:, 0].min()}..{bad[:, 0].max()}, cols {bad[:, 1].min()}..{bad[:, 1].max()}; "
+                                 f"first ({r},{c}) got {got[r, max(0, c - 2):c + 3].tolist()} want {want[r, max(0, c - 2):c + 3].tolist()}")
     r = out.result()
     assert r["max_pos"] == int(g["meta"][3]) and r["max_score"] == int(g["meta"][4])
     path = engine.traceback(out)

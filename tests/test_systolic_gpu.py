@@ -168,3 +168,17 @@ def test_character_compare_producers_still_exact(engine, oracle, cols, rows):
         check_against_oracle(engine, oracle, a, b, scores=(3, 1, -2))
     finally:
         engine.set_option("debug_flags", 0)
+
+
+def test_many_launches_of_mixed_shapes_across_the_tag_wrap(engine, swamd):
+    """The perm producer's exported edge values carry an 8-bit launch tag in their top byte and the workspace is reused
+    by launches of different shapes; 800 back-to-back fills of three golden problems (the tag wraps after 255) must all
+    be bit-exact.  Round 2 regression: values computed below the matrix from left-over LDS contents once grew past 24
+    bits, bumped their tag byte and were accepted by the next launch -- about one wrong fill in 150."""
+    from oracle_lib import golden
+    gs = [golden(n) for n in ("rand_256x256_s1", "rand_300x200_s1", "rand_129x64_s11")]
+    for it in range(270):
+        for g in gs:
+            out = engine.fill(g["a"], g["b"])
+            assert np.array_equal(out.H.cpu().numpy(), g["H"]) and np.array_equal(out.P.cpu().numpy(), g["P0"]), f"iteration {it}"
+            assert out.result()["max_pos"] == int(g["meta"][3])
