@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- GCUPS of the Smith-Waterman DP fill on MI355X (BASELINE.json metric).
 
-One "step" = one full DP fill (H and P matrices + arg-max) of one cols x rows random DNA pair whose
-sequences are already resident in HBM.  N=1 runs BASELINE config[1]: 16384 x 16384, int32 H/P.
-For N>1 (one process per GPU, launched by torch.distributed.run) every rank fills its own pair
-of the same size (weak scaling, no data-path collective); ranks synchronise only around the
-timed region.  Prints ONE JSON line on rank 0.
+One "step" = one full DP fill (H and P matrices + arg-max) of ONE cols x rows random DNA pair whose sequences are
+already resident in HBM.
+
+  N = 1   BASELINE config[1]: 16384 x 16384, int32 H + int32 P on one GPU.  `value` is measured on output buffers from
+          the C-ABI allocator sw_alloc_outputs (what a C caller gets); `config.value_first_allocation` is the same fill
+          into a plain first allocation.
+  N > 1   BASELINE config[3]: ONE 262144 x 262144 matrix cut into N row bands, one per rank (strong scaling: the work
+          is fixed, N varies), band-resident launches with the halo rows forwarded rank to rank over RCCL.  550 GB of
+          int32 H + int32 P do not fit two GPUs, so every N > 1 point uses int32 H + int8 P (5 B/cell, 344 GB in total:
+          172 GB per GPU at N = 2); `config.workload` says so.  (--mode replicas keeps the old one-pair-per-rank run.)
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib
@@ -21,26 +28,52 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def _best_of(cmd, n, env=None):
+    best = None
+    for _ in range(n):
+        t = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env).stdout
+        m = re.search(r"scoring matrix computation:\s*([0-9.]+)", t)
+        if m:
+            s = float(m.group(1))
+            best = s if best is None else min(best, s)
+    return best
+
+
 def cpu_baseline(cols, rows):
-    """Time the REAL reference (oracle/_ref, built from the reference's serial_smithW.c in the build
-    container) on this box's host cores; falls back to the C port (oracle/liboracle.so)."""
+    """The REAL reference programs (oracle/_ref, built from /root/reference in the build container) timed on this box's
+    host cores, best of 3 like the reference's run-v1.sh:33; falls back to the C port (oracle/liboracle.so)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "serial_smithW")
     out = {}
+    ncores = len(os.sched_getaffinity(0))
     if os.path.exists(ref):
-        t = subprocess.run([ref, str(cols), str(rows)], capture_output=True, text=True, timeout=600).stdout
-        sec = float(re.search(r"scoring matrix computation:\s*([0-9.]+)", t).group(1))
+        sec = _best_of([ref, str(cols), str(rows)], 3)
         out = {"value": cols * rows / sec / 1e9, "unit": "GCUPS", "cores": 1, "kind": "reference",
-               "sample": f"serial_smithW {cols} {rows} (the full workload, fill loop only), {sec:.3f} s"}
+               "sample": f"serial_smithW {cols} {rows} (the full workload, fill loop only), best of 3: {sec:.3f} s"}
         omp = os.path.join(ROOT, "oracle", "_ref", "omp_smithW-v1")
         if os.path.exists(omp):
-            nthr = min(len(os.sched_getaffinity(0)), 16)  # the 1-GPU box's CPU share
-            env = dict(os.environ, OMP_NUM_THREADS=str(nthr), OMP_PROC_BIND="close")
-            t = subprocess.run([omp, str(cols), str(rows)], capture_output=True, text=True, timeout=600, env=env).stdout
-            m = re.search(r"scoring matrix computation:\s*([0-9.]+)", t)
-            if m:
-                out["omp"] = {"value": cols * rows / float(m.group(1)) / 1e9, "unit": "GCUPS", "cores": nthr,
-                              "kind": "reference",
-                              "sample": f"omp_smithW-v1-refinedOrig -DSKIP_BACKTRACK {cols} {rows}, {float(m.group(1)):.3f} s"}
+            # one barrier per anti-diagonal: more threads are not faster.  Best of 3 with 16 threads, and ONE run on a bounded
+            # sample with every core this process may use (the reference's own scripts use all of them, run-v1.sh:33)
+            env = dict(os.environ, OMP_NUM_THREADS="16", OMP_PROC_BIND="close")
+            sec = _best_of([omp, str(cols), str(rows)], 3, env)
+            if sec:
+                out["omp"] = {"value": cols * rows / sec / 1e9, "unit": "GCUPS", "cores": 16, "kind": "reference",
+                              "sample": f"omp_smithW-v1-refinedOrig -DSKIP_BACKTRACK {cols} {rows}, 16 threads, best of 3: {sec:.3f} s"}
+            if ncores > 16:
+                n = min(cols, 4096)
+                env = dict(os.environ, OMP_NUM_THREADS=str(ncores), OMP_PROC_BIND="close")
+                sec = _best_of([omp, str(n), str(n)], 1, env)
+                if sec:
+                    out["omp_all_cores"] = {"value": n * n / sec / 1e9, "unit": "GCUPS", "cores": ncores, "kind": "reference",
+                                            "sample": f"omp_smithW-v1-refinedOrig -DSKIP_BACKTRACK {n} {n}, all {ncores} hardware threads: {sec:.3f} s"}
+        ompc = os.path.join(ROOT, "oracle", "_ref", "omp_smithW")
+        if os.path.exists(ompc):
+            # omp_smithW.c takes an `omp critical` per cell (omp_smithW.c:384-387): a bounded sample, 4096 x 4096
+            env = dict(os.environ, OMP_NUM_THREADS=str(min(ncores, 16)), OMP_PROC_BIND="close")
+            n = min(cols, 4096)
+            sec = _best_of([ompc, str(n), str(n)], 1, env)
+            if sec:
+                out["omp_critical"] = {"value": n * n / sec / 1e9, "unit": "GCUPS", "cores": min(ncores, 16), "kind": "reference",
+                                       "sample": f"omp_smithW (per-cell critical arg-max) {n} {n}, {min(ncores, 16)} threads: {sec:.3f} s"}
     else:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib
@@ -54,10 +87,38 @@ def cpu_baseline(cols, rows):
     return out
 
 
-def alt_modes(args, sw, eng, torch, dist, rank, world, local):
-    """--mode bands / batch: same timing contract (warm-up, K timed steps, barrier + synchronize, max over ranks)."""
+def chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows):
+    """One extra fill with the kernel's debug stamps: the producer's time per anti-diagonal step (strip 0 never waits
+    for a neighbour) and the lag per strip hand-off, for the dependency bound N^2 / ((2N-1) tau)."""
     import numpy as np
+    S = (cols + 62) // 63
+    dbg = torch.zeros(6 * S + 64, dtype=torch.int64, device=out.res.device)
+    eng.set_option("debug_buf", dbg.data_ptr())
+    eng.fill_into(out, d_a, d_b)
+    eng.synchronize()
+    eng.set_option("debug_buf", 0)
+    t = dbg.cpu().numpy()[:2 * S].reshape(S, 2).astype(np.float64) * 10.0   # 100 MHz ticks -> ns
+    steps = rows + 63 + (S - 1)
+    tau = (t[0, 1] - t[0, 0]) / max(1, steps)
+    lag = float(np.diff(t[:, 1]).mean()) if S > 1 else 0.0
+    return tau, lag
+
+
+def traffic_for(workload_key):
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        return pm.get(workload_key, {}).get("traffic_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def run_pair(args, sw, eng, torch, dist, rank, world, local):
     cols, rows = args.cols, args.rows
+    a, b = sw.generate(cols, rows, 1 + rank)          # reference generator; rank r uses seed 1+r (replicas mode)
+    d_a, _ = eng.to_device(a)
+    d_b, _ = eng.to_device(b)
+    h_dtype = torch.int64 if args.h64 else torch.int32
+    p_dtype = torch.int8 if args.p8 else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -65,45 +126,158 @@ def alt_modes(args, sw, eng, torch, dist, rank, world, local):
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.mode == "batch":
-        npairs = args.pairs
-        A = np.stack([sw.generate(cols, rows, 1 + rank * npairs + k)[0] for k in range(npairs)])
-        B = np.stack([sw.generate(cols, rows, 1 + rank * npairs + k)[1] for k in range(npairs)])
-        step = lambda: eng.batch(A, B, store=args.store)   # includes the H2D of the sequences (a few MB)
-        cells = npairs * cols * rows
-        what = f"{npairs} independent {cols}x{rows} pairs per GPU in one launch ({'H/P stored' if args.store else 'score-only'})"
+    def timed(out, steps, warmup):
+        for _ in range(warmup):
+            eng.fill_into(out, d_a, d_b)
+        barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for e0, e1 in evs:
+            e0.record()
+            eng.fill_into(out, d_a, d_b)
+            e1.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        return dt, [e0.elapsed_time(e1) for e0, e1 in evs]
+
+    # (1) a plain first allocation: what a caller of sw_device_malloc gets
+    first = eng.alloc(cols, rows, h_dtype, p_dtype)
+    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    first.H.fill_(0); torch.cuda.synchronize()
+    f0.record()
+    for _ in range(5):
+        first.H.fill_(0)
+    f1.record(); torch.cuda.synchronize()
+    fill_gbs = 5 * first.H.numel() * first.H.element_size() / (f0.elapsed_time(f1) * 1e-3) / 1e9
+    dt_first, ms_first = timed(first, max(3, args.steps // 2), args.warmup)
+    value_first = world * len(ms_first) * cols * rows / dt_first / 1e9
+    if args.placement_trials == 1:
+        out, placement_ms = first, None
     else:
-        multi = importlib.import_module("smith-waterman_amd.multi")
-        if world == 1 and not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29613")
-            dist.init_process_group("gloo", rank=0, world_size=1)
-        a, _ = sw.generate(cols, rows, 1)
-        bb = np.concatenate([sw.generate(cols, rows, 1 + r)[1] for r in range(world)])   # world*rows rows in total
-        pipe = multi.BandPipeline(dist, rank, world, a, bb, nchunks=args.chunks, make_tiles=lambda *x: multi.GpuTiles(eng, *x))
-        step = pipe.fill
-        cells = cols * rows * world
-        what = f"ONE {cols} x {rows * world} matrix as {world} row bands x {len(pipe.chunks)} column chunks, p2p halo rows"
+        del first
+        torch.cuda.empty_cache()
+        # (2) the C-ABI allocator: candidate placements tried with real fills, outside the timed region
+        out, placement_ms = eng.alloc_outputs(d_a, d_b, cols, rows, h_dtype, p_dtype, trials=args.placement_trials)
+    dt, kern_ms = timed(out, args.steps, args.warmup)
+    res = out.result()
+    tau_ns, lag_ns = chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows) if args.engine == 0 else (0.0, 0.0)
+    if world > 1:
+        tmax = torch.tensor([dt], device=f"cuda:{local}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        return
+    cells = cols * rows
+    bytes_per_cell = (8 if args.h64 else 4) + (1 if args.p8 else 4)   # mandatory H + P output only
+    avg_ms = sum(kern_ms) / len(kern_ms)
+    achieved = bytes_per_cell * cells / (avg_ms * 1e-3) / 1e9
+    key = f"{cols}x{rows} {'int64' if args.h64 else 'int32'} H + {'int8' if args.p8 else 'int32'} P"
+    line = {
+        "metric": "GCUPS (DP cell updates/s) on NxN random DNA pair", "value": world * args.steps * cells / dt / 1e9,
+        "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int64" if args.h64 else "int32", "data": "synthetic",
+        "config": {"workload": f"{cols}x{rows} random DNA pair (reference generator, seed 1+rank), linear gap 3/-3/-2, "
+                               f"{'int64' if args.h64 else 'int32'} H + {'int8' if args.p8 else 'int32'} P written to HBM, arg-max tracked",
+                   "per_gpu": "one pair per GPU" + (" (replicas)" if world > 1 else ""), "max_pos": res["max_pos"], "max_score": res["max_score"],
+                   "grid": eng.get_option("last_grid"), "strips": eng.get_option("last_strips"),
+                   "output_buffers": "sw_alloc_outputs (C-ABI allocator, placement chosen by trial fills)" if placement_ms is not None else "plain first allocation",
+                   "placement_trials_ms": placement_ms, "value_first_allocation": value_first,
+                   "ms_first_allocation": sum(ms_first) / len(ms_first)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_for(key),
+                     "kernel": "sw_systolic" if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
+                     "algorithmic_bytes_per_cell": bytes_per_cell, "measured_contiguous_fill_GBs": fill_gbs,
+                     "tau_step_ns": tau_ns, "strip_handoff_lag_ns": lag_ns,
+                     "dependency_bound_gcups": (cells / ((cols + rows - 1) * tau_ns)) if tau_ns > 0 else None},
+    }
+    if not args.no_cpu and world == 1:
+        cb = cpu_baseline(cols, rows)
+        for k in ("omp", "omp_all_cores", "omp_critical"):
+            v = cb.pop(k, None)
+            if v:
+                line["cpu_baseline_" + k] = v
+        line["cpu_baseline"] = cb
+    print(json.dumps(line), flush=True)
+
+
+def run_bands(args, sw, eng, torch, dist, rank, world, local):
+    """ONE matrix as `world` row bands, band-resident launches (sw_fill_band_device), halo rows rank to rank."""
+    import numpy as np
+    multi = importlib.import_module("smith-waterman_amd.multi")
+    cols, rows = args.cols, args.rows
+    p8 = args.p8 or (world > 1 and not args.p32)
+    a, b = sw.generate(cols, rows, 1)
+    pipe = multi.BandResident(dist, rank, world, eng, a, b, nchunks=args.chunks, p_dtype=torch.int8 if p8 else None,
+                              want_h=not args.no_h, reserve_cus=args.reserve_cus)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(args.warmup):
-        step()
+        pipe.fill()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        score, pos = pipe.fill()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], device=f"cuda:{local}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    if rank == 0:
-        tot = cells * (world if args.mode == "batch" else 1)
-        print(json.dumps({"metric": "GCUPS (DP cell updates/s)", "value": args.steps * tot / dt / 1e9, "unit": "GCUPS", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-                          "config": {"workload": what, "mode": args.mode}}), flush=True)
-    eng.close()
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    if rank != 0:
+        return
+    cells = cols * rows
+    bpc = (0 if args.no_h else 4) + (1 if p8 else 4)
+    achieved = bpc * cells / (dt / args.steps) / 1e9       # whole job; per GPU = / world
+    line = {"metric": "GCUPS (DP cell updates/s) on NxN random DNA pair", "value": args.steps * cells / dt / 1e9, "unit": "GCUPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": f"ONE {cols}x{rows} random DNA pair (reference generator, seed 1), linear gap 3/-3/-2, as {world} row band(s) of "
+                                   f"{-(-rows // world)} rows, one band-resident launch per GPU, "
+                                   f"{'no H' if args.no_h else 'int32 H'} + {'int8' if p8 else 'int32'} P written to HBM ({bpc} B/cell, "
+                                   f"{bpc * (cols + 1) * (rows + 1) / world / 2**30:.0f} GiB per GPU), arg-max tracked, halo rows as granules over "
+                                   f"{'RCCL send/recv' if world > 1 else 'nothing (single band)'} in {len(pipe.chunks)} column chunks",
+                       "mode": "bands", "max_score": score, "max_pos": pos},
+            "roofline": {"bound": "hbm", "achieved": achieved / world, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / world / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "sw_systolic", "algorithmic_bytes_per_cell": bpc, "per": "GPU (whole job / n_gpus)"}}
+    print(json.dumps(line), flush=True)
+
+
+def run_batch(args, sw, eng, torch, dist, rank, world, local):
+    import numpy as np
+    cols, rows, npairs = args.cols, args.rows, args.pairs
+    A = np.stack([sw.generate(cols, rows, 1 + rank * npairs + k)[0] for k in range(npairs)])
+    B = np.stack([sw.generate(cols, rows, 1 + rank * npairs + k)[1] for k in range(npairs)])
+    p_dtype = torch.int8 if args.p8 else None
+    step = lambda: eng.batch(A, B, store=args.store, p_dtype=p_dtype, store_h=not args.no_h, traceback=args.traceback)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank != 0:
+        return
+    cells = npairs * cols * rows
+    bpc = ((0 if args.no_h else 4) + (1 if args.p8 else 4)) if args.store else 0
+    what = f"{npairs} independent {cols}x{rows} pairs (pair k seeded 1+k) in one call: "
+    what += (f"{'int32 H + ' if not args.no_h else ''}{'int8' if args.p8 else 'int32'} P stored ({bpc} B/cell)" if args.store else "score + exact maxPos only (no matrices)")
+    what += ", per-pair traceback" if args.traceback else ""
+    line = {"metric": "GCUPS (DP cell updates/s)", "value": args.steps * cells / dt / 1e9, "unit": "GCUPS", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic", "config": {"workload": what + " (host-to-device copy of the sequences included)", "mode": "batch"}}
+    if bpc:
+        ach = bpc * cells / (dt / args.steps) / 1e9
+        line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                            "kernel": "sw_systolic", "algorithmic_bytes_per_cell": bpc}
+    print(json.dumps(line), flush=True)
 
 
 def main():
@@ -111,29 +285,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cols", type=int, default=16384)
-    ap.add_argument("--rows", type=int, default=16384)
+    ap.add_argument("--cols", type=int, default=0)
+    ap.add_argument("--rows", type=int, default=0)
     ap.add_argument("--h64", action="store_true", help="int64 H (BASELINE config 3 element type)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--mode", default="pair", choices=["pair", "bands", "batch"],
-                    help="pair: one independent cols x rows pair per GPU (default, the BASELINE metric); "
-                         "bands: ONE (gpus*rows) x cols matrix as row bands over the GPUs with p2p halo rows; "
-                         "batch: --pairs independent pairs per GPU in one launch (BASELINE config 5)")
-    ap.add_argument("--chunks", type=int, default=8, help="bands mode: column chunks per band")
-    ap.add_argument("--pairs", type=int, default=512, help="batch mode: pairs per GPU")
-    ap.add_argument("--store", action="store_true", help="batch mode: also write H/P of every pair")
+    ap.add_argument("--mode", default="auto", choices=["auto", "pair", "bands", "batch", "replicas"],
+                    help="auto: pair on one GPU, bands (one matrix sharded over the ranks) on several; replicas: one independent pair "
+                         "per GPU; batch: --pairs independent pairs in one call (BASELINE config 5)")
+    ap.add_argument("--chunks", type=int, default=64, help="bands: column chunks the halo row is forwarded in")
+    ap.add_argument("--reserve-cus", type=int, default=16, help="bands, several GPUs: CUs left to the halo transfers")
+    ap.add_argument("--p32", action="store_true", help="bands on several GPUs: int32 P instead of int8 (550 GB at 262144^2)")
+    ap.add_argument("--no-h", action="store_true", help="bands / batch: do not write H (P-only)")
+    ap.add_argument("--pairs", type=int, default=512, help="batch mode: pairs")
+    ap.add_argument("--store", action="store_true", help="batch mode: also write the matrices of every pair")
+    ap.add_argument("--traceback", action="store_true", help="batch mode: per-pair traceback (needs --store)")
     ap.add_argument("--engine", type=int, default=0, help="0 systolic (default), 1 strip_scan")
     ap.add_argument("--ns", type=int, default=0, help="systolic: strips per workgroup")
     ap.add_argument("--nc", type=int, default=0, help="systolic: consumer waves per strip")
-    ap.add_argument("--p8", action="store_true", help="compact predecessor matrix: int8 P (sw_fill_device_ex), 5 or 9 B/cell")
-    ap.add_argument("--placement-trials", type=int, default=12,
-                    help="pair mode: candidate H/P allocations tried before the timed region (1 = take the first)")
+    ap.add_argument("--p8", action="store_true", help="compact predecessor matrix: int8 P")
+    ap.add_argument("--placement-trials", type=int, default=6,
+                    help="pair mode: candidate H/P placements sw_alloc_outputs may try before the timed region (1 = plain allocation)")
     ap.add_argument("--store-policy", type=int, default=0, help="systolic H/P stores: 0 auto, 1 write-back, 2 streaming")
-    ap.add_argument("--xcd-order", type=int, default=0, help="systolic: neighbouring strip groups on one XCD")
-    ap.add_argument("--importers", type=int, default=0, help="systolic, one strip per workgroup: importer waves (1 or 2)")
-    ap.add_argument("--pace", type=int, default=-1, help="systolic: strip-0 pacing in ps per row (0 = off, -1 = library default)")
+    ap.add_argument("--importers", type=int, default=0)
     ap.add_argument("--debug-flags", type=int, default=0)
-    ap.add_argument("--wpb", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
     args = ap.parse_args()
 
@@ -150,111 +324,25 @@ def main():
     sw = importlib.import_module("smith-waterman_amd")
     eng = sw.Engine(local)
     eng.set_option("engine", args.engine)
-    if args.pace >= 0:
-        eng.set_option("pace_ps", args.pace)
-    if args.importers:
-        eng.set_option("importers", args.importers)
-    if args.store_policy:
-        eng.set_option("store_policy", args.store_policy)
-    if args.xcd_order:
-        eng.set_option("xcd_order", args.xcd_order)
-    if args.ns:
-        eng.set_option("strips_per_group", args.ns)
-    if args.nc:
-        eng.set_option("consumers", args.nc)
-    if args.debug_flags:
-        eng.set_option("debug_flags", args.debug_flags)
-    if args.wpb:
-        eng.set_option("waves_per_block", args.wpb)
-    if args.max_blocks:
-        eng.set_option("max_blocks", args.max_blocks)
-
-    cols, rows = args.cols, args.rows
-    if args.mode != "pair":
-        return alt_modes(args, sw, eng, torch, dist, rank, world, local)
-    a, b = sw.generate(cols, rows, 1 + rank)          # reference generator; rank r uses seed 1+r
-    d_a, _ = eng.to_device(a)
-    d_b, _ = eng.to_device(b)
-    # Output buffers, outside the timed region.  Where the driver places H and P in physical memory moves the fill
-    # time by ~15 % (two modes per allocation), so the buffers are chosen among a few candidate
-    # allocations by trial fills; the timed steps below then all run on the chosen pair.
-    placement_ms = None
-    if args.placement_trials > 1:
-        out, placement_ms = eng.alloc_tuned(d_a, d_b, cols, rows, torch.int64 if args.h64 else torch.int32, trials=args.placement_trials,
-                                            p_dtype=torch.int8 if args.p8 else None)
-    else:
-        out = eng.alloc(cols, rows, torch.int64 if args.h64 else torch.int32, torch.int8 if args.p8 else None)
-
-    def barrier():
-        torch.cuda.synchronize()
+    for name, v in (("importers", args.importers), ("store_policy", args.store_policy), ("strips_per_group", args.ns), ("consumers", args.nc),
+                    ("debug_flags", args.debug_flags), ("max_blocks", args.max_blocks)):
+        if v:
+            eng.set_option(name, v)
+    mode = args.mode
+    if mode == "auto":
+        mode = "pair" if world == 1 else "bands"
+    if mode == "replicas":
+        mode = "pair"
+    if not args.cols:
+        args.cols = 262144 if mode == "bands" and world > 1 else (1024 if mode == "batch" else 16384)
+    if not args.rows:
+        args.rows = args.cols
+    try:
+        {"pair": run_pair, "bands": run_bands, "batch": run_batch}[mode](args, sw, eng, torch, dist, rank, world, local)
+    finally:
+        eng.close()
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # what a plain contiguous fill of H sustains on this box (reported beside the 8 TB/s spec peak)
-    f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    out.H.fill_(0); torch.cuda.synchronize()
-    f0.record()
-    for _ in range(5):
-        out.H.fill_(0)
-    f1.record(); torch.cuda.synchronize()
-    fill_gbs = 5 * out.H.numel() * out.H.element_size() / (f0.elapsed_time(f1) * 1e-3) / 1e9
-
-    for _ in range(args.warmup):
-        eng.fill_into(out, d_a, d_b)
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()
-        eng.fill_into(out, d_a, d_b)
-        e1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    res = out.result()
-    kern_ms = [e0.elapsed_time(e1) for e0, e1 in evs]
-    if world > 1:
-        tmax = torch.tensor([dt], device=f"cuda:{local}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    if rank == 0:
-        traffic = None   # HBM bytes per launch from the PMC passes (scripts/gpu_pmc.sh), when they exist for this workload
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if not args.p8 and pm["workload"] == f"{cols}x{rows} {'int64' if args.h64 else 'int32'} engine={'systolic' if args.engine == 0 else 'strip_scan'}":
-                traffic = pm["traffic_bytes_per_launch"]
-        except Exception:
-            pass
-        cells = cols * rows
-        bytes_per_cell = (8 if args.h64 else 4) + (1 if args.p8 else 4)   # mandatory H + P output only
-        avg_ms = sum(kern_ms) / len(kern_ms)
-        achieved = bytes_per_cell * cells / (avg_ms * 1e-3) / 1e9
-        line = {
-            "metric": "GCUPS (DP cell updates/s) on NxN random DNA pair", "value": world * args.steps * cells / dt / 1e9,
-            "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int64" if args.h64 else "int32", "data": "synthetic",
-            "config": {"workload": f"{cols}x{rows} random DNA pair (reference generator, seed 1+rank), linear gap 3/-3/-2, "
-                                   f"{'int64' if args.h64 else 'int32'} H + {'int8' if args.p8 else 'int32'} P written to HBM, arg-max tracked",
-                       "per_gpu": "one independent pair per GPU", "max_pos": res["max_pos"], "max_score": res["max_score"],
-                       "grid": eng.get_option("last_grid"), "strips": eng.get_option("last_strips"),
-                       "placement_trials_ms": placement_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sw_systolic" if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
-                         "algorithmic_bytes_per_cell": bytes_per_cell, "measured_contiguous_fill_GBs": fill_gbs},
-        }
-        if not args.no_cpu and world == 1:
-            cb = cpu_baseline(cols, rows)
-            omp = cb.pop("omp", None)
-            line["cpu_baseline"] = cb
-            if omp:
-                line["cpu_baseline_omp"] = omp
-        print(json.dumps(line), flush=True)
-    eng.close()
-    if world > 1:
-        dist.destroy_process_group()
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

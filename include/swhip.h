@@ -179,6 +179,16 @@ int sw_traceback_host_ex(void* P, int p_elem_bytes, int64_t cols, int64_t rows, 
 int sw_row_checksums_device(sw_ctx* ctx, const void* d_X, int elem_bytes, int64_t rows1, int64_t m,
                             uint64_t* d_cs, void* stream);
 
+/* ---- output buffers placed for speed -------------------------------------------------------
+ * Where H and P lie in physical memory moves a 16384^2 fill by up to 25 % (their two store streams can meet in the
+ * same DRAM banks).  sw_alloc_outputs allocates up to `trials` candidate pairs (0 = 6; 1 = a plain allocation, no trial
+ * fills), runs three fills of the caller's problem into each on the default stream and keeps the fastest; trial_ms
+ * (optional, `trials` floats) receives the time of every candidate tried, 0 for those not needed.  The contents of the
+ * returned buffers are the last trial fill.  Release with sw_free_outputs (d_P may sit inside a larger allocation). */
+int sw_alloc_outputs(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
+                     int h_elem_bytes, int p_elem_bytes, int trials, void** d_H, void** d_P, float* trial_ms);
+int sw_free_outputs(sw_ctx* ctx, void* d_H, void* d_P);
+
 /* ---- device memory plumbing for hosts without a HIP binding (cgo / JNI / ctypes callers) --- */
 int sw_device_malloc(sw_ctx* ctx, size_t bytes, void** d_ptr);
 int sw_device_free(sw_ctx* ctx, void* d_ptr);

@@ -65,6 +65,9 @@ ABI = {
     "sw_traceback_device_ex": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "sw_fill_device_ex": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sw_row_checksums_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
+    "sw_alloc_outputs": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _i32, _i32, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                ctypes.POINTER(ctypes.c_float)]),
+    "sw_free_outputs": (_i32, [_vp, _vp, _vp]),
     "sw_device_malloc": (_i32, [_vp, _sz, ctypes.POINTER(_vp)]),
     "sw_device_free": (_i32, [_vp, _vp]),
     "sw_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),
@@ -165,6 +168,28 @@ class Fill:
         return {"max_pos": r[0], "max_score": r[1], "path_len": r[2]}
 
 
+class _RawDevice:
+    """A device allocation of the library seen by torch (zero-copy, __cuda_array_interface__)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+        self._owner = owner
+
+
+class _Outputs:
+    """Keeps a sw_alloc_outputs pair alive; released with sw_free_outputs."""
+
+    def __init__(self, engine, dH, dP):
+        self.engine, self.dH, self.dP = engine, dH, dP
+
+    def __del__(self):
+        try:
+            if self.engine._h:
+                lib().sw_free_outputs(self.engine._h, self.dH, self.dP)
+        except Exception:
+            pass
+
+
 class Engine:
     """One GPU's fill engine (sw_ctx). Uses torch only for device buffers / current stream."""
 
@@ -251,6 +276,27 @@ class Engine:
                 del spacer
                 t.cuda.empty_cache()
         return out
+
+    def alloc_outputs(self, d_a, d_b, cols: int, rows: int, h_dtype=None, p_dtype=None, trials: int = 0, scores=DEFAULT_SCORES):
+        """Output buffers through the C-ABI allocator sw_alloc_outputs (what a C caller gets): candidate placements
+        tried with real fills of this problem, the fastest kept.  Returns (Fill, [ms of every candidate tried])."""
+        t = self.torch
+        h_dtype = h_dtype or t.int32
+        p_dtype = p_dtype or t.int32
+        n = trials if trials > 0 else 6
+        ms = (ctypes.c_float * n)()
+        dH, dP = _vp(), _vp()
+        sc = _Scores(*scores)
+        self.synchronize()
+        _check(lib().sw_alloc_outputs(self._h, d_a.data_ptr(), cols, d_b.data_ptr(), rows, ctypes.byref(sc), 8 if h_dtype == t.int64 else 4,
+                                      1 if p_dtype == t.int8 else 4, trials, ctypes.byref(dH), ctypes.byref(dP), ms))
+        owner = _Outputs(self, dH.value, dP.value)
+        shape = (rows + 1, cols + 1)
+        H = t.as_tensor(_RawDevice(dH.value, shape, "<i8" if h_dtype == t.int64 else "<i4", owner), device=f"cuda:{self.device}")
+        P = t.as_tensor(_RawDevice(dP.value, shape, "|i1" if p_dtype == t.int8 else "<i4", owner), device=f"cuda:{self.device}")
+        out = Fill(H, P, t.zeros(3, dtype=t.int64, device=f"cuda:{self.device}"), cols, rows)
+        out._owner = owner
+        return out, [x for x in ms if x > 0]
 
     def alloc_tuned(self, d_a, d_b, cols: int, rows: int, h_dtype=None, trials: int = 4, fills: int = 3, p_dtype=None):
         """alloc() with placement tuning: the fill's speed depends on where the driver put H and P in

@@ -3,8 +3,10 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 #include "sw_kernels.h"
 
 namespace swh { void set_err(const char* fmt, ...); }
@@ -60,6 +62,7 @@ struct sw_ctx {
     int64_t opt_waves_per_block = 4;
     int64_t opt_max_blocks = 0;         // 0 -> 2 * CUs
     int64_t last_grid = 0, last_strips = 0;
+    std::map<void*, void*> out_base;    // sw_alloc_outputs: pointer handed out -> allocation to free
 };
 
 extern "C" {
@@ -566,6 +569,88 @@ int sw_traceback_device_ex(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols,
 int sw_traceback_device(sw_ctx* c, int32_t* d_P, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path,
                         int64_t path_cap, sw_result* d_result, void* stream_) {
     return sw_traceback_device_ex(c, d_P, 4, cols, rows, max_pos, d_path, path_cap, d_result, stream_);
+}
+
+// Output matrices placed for speed.  Where the driver puts H and P in physical memory moves the time of a 16384^2 fill by
+// up to 25 % (two store streams that meet in the same DRAM banks): allocate up to `trials`
+// candidate pairs -- P two MiB out of phase with H, and from the second candidate on a spacer block of 3..28 GiB between
+// them so that they come from different regions of the HBM --, time three fills of the caller's problem into each and
+// keep the fastest.
+int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores, int h_elem_bytes,
+                     int p_elem_bytes, int trials, void** d_H, void** d_P, float* trial_ms) {
+    if (!c || !d_H || !d_P || cols < 0 || rows < 0 || (h_elem_bytes != 4 && h_elem_bytes != 8) || (p_elem_bytes != 4 && p_elem_bytes != 1) ||
+        (trials > 1 && (!d_a || !d_b))) {
+        set_err("sw_alloc_outputs: bad argument");
+        return SW_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (trials <= 0) trials = 6;
+    const size_t cells = (size_t)(cols + 1) * (size_t)(rows + 1);
+    const size_t hbytes = cells * (size_t)h_elem_bytes, pbytes = cells * (size_t)p_elem_bytes;
+    const size_t phase = 4u << 20;
+    struct Cand { void* H; void* Pbase; void* P; void* spacer; float ms; };
+    std::vector<Cand> cands;
+    sw_result* d_res = nullptr;
+    if (hipMalloc((void**)&d_res, sizeof(sw_result)) != hipSuccess) { set_err("sw_alloc_outputs: allocation failed"); return SW_ENOMEM; }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    size_t spacer_total = 0;
+    int best = -1, rc = SW_OK;
+    for (int i = 0; i < trials; ++i) {
+        Cand k = {nullptr, nullptr, nullptr, nullptr, 0.f};
+        if (hipMalloc(&k.H, hbytes ? hbytes : 1) != hipSuccess) { (void)hipGetLastError(); break; }
+        const size_t sp = (i > 0 && hbytes < (4ull << 30)) ? (size_t)((i % 6) * 5 + 3) << 30 : 0;
+        if (sp && spacer_total + sp <= (96ull << 30) && hipMalloc(&k.spacer, sp) == hipSuccess) spacer_total += sp;
+        else { (void)hipGetLastError(); k.spacer = nullptr; }
+        if (hipMalloc(&k.Pbase, pbytes + phase) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(k.H); if (k.spacer) (void)hipFree(k.spacer); break; }
+        // P two MiB out of phase with H modulo 4 MiB
+        const uintptr_t want = ((uintptr_t)k.H + (2u << 20)) % phase;
+        const uintptr_t off = (want + phase - ((uintptr_t)k.Pbase % phase)) % phase;
+        k.P = (char*)k.Pbase + off;
+        if (trials > 1) {
+            for (int f = 0; f < 4 && rc == SW_OK; ++f) {
+                if (f == 1) (void)hipEventRecord(e0, nullptr);
+                rc = sw_fill_device_ex(c, d_a, cols, d_b, rows, scores, k.H, h_elem_bytes, k.P, p_elem_bytes, nullptr, d_res, nullptr);
+            }
+            (void)hipEventRecord(e1, nullptr);
+            if (rc == SW_OK && hipEventSynchronize(e1) != hipSuccess) { set_err("sw_alloc_outputs: trial fill failed"); rc = SW_EDEVICE; }
+            if (rc == SW_OK) { (void)hipEventElapsedTime(&k.ms, e0, e1); k.ms /= 3.f; }
+        }
+        cands.push_back(k);
+        if (rc != SW_OK) break;
+        if (trial_ms) trial_ms[i] = k.ms;
+        if (best < 0 || k.ms < cands[best].ms) best = (int)cands.size() - 1;
+        if (cands.size() >= 3) {   // clearly in the fast mode: stop looking
+            std::vector<float> t;
+            for (auto& x : cands) t.push_back(x.ms);
+            std::sort(t.begin(), t.end());
+            if (cands[best].ms < 0.92f * t[t.size() / 2]) { for (int j = i + 1; j < trials && trial_ms; ++j) trial_ms[j] = 0.f; break; }
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(d_res);
+    for (int i = 0; i < (int)cands.size(); ++i) {
+        if (cands[i].spacer) (void)hipFree(cands[i].spacer);
+        if (i != best || rc != SW_OK) { (void)hipFree(cands[i].H); (void)hipFree(cands[i].Pbase); }
+    }
+    if (rc != SW_OK) return rc;
+    if (best < 0) { set_err("sw_alloc_outputs: %zu + %zu bytes do not fit", hbytes, pbytes); return SW_ENOMEM; }
+    *d_H = cands[best].H; *d_P = cands[best].P;
+    c->out_base[cands[best].P] = cands[best].Pbase;
+    return SW_OK;
+}
+
+int sw_free_outputs(sw_ctx* c, void* d_H, void* d_P) {
+    if (!c) { set_err("sw_free_outputs: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (d_H) HIP_TRY(hipFree(d_H));
+    if (d_P) {
+        auto it = c->out_base.find(d_P);
+        void* base = (it != c->out_base.end()) ? it->second : d_P;
+        if (it != c->out_base.end()) c->out_base.erase(it);
+        HIP_TRY(hipFree(base));
+    }
+    return SW_OK;
 }
 
 int sw_device_malloc(sw_ctx* c, size_t bytes, void** d_ptr) {

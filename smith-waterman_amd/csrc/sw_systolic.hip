@@ -461,6 +461,32 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
 // progress is sampled (Rc) BEFORE the next block's groups are fetched and evaluated at the next block's start: if it
 // covered that whole block then, what was fetched is valid; else the slow path polls and fetches again.
 // LDS order: [k0] R3 [k1-3] W0 [k4] Rc R0' [k5-7] W1 [k8] R1' [k9-11] W2 (BPF) [k12] R2' [k13-15] W3 Wp
+/* tools/ubench_prod.hip: knock single parts of the block out to see what each costs (never in the product build) */
+#ifdef PP_NO_CHK
+#define PP_K_CHK(X) ""
+#else
+#define PP_K_CHK(X) X
+#endif
+#ifdef PP_NO_CODE
+#define PP_K_CODE(X) ""
+#else
+#define PP_K_CODE(X) X
+#endif
+#ifdef PP_NO_RING
+#define PP_K_RING(X) ""
+#else
+#define PP_K_RING(X) X
+#endif
+#ifdef PP_NO_PROG
+#define PP_K_PROG(X) ""
+#else
+#define PP_K_PROG(X) X
+#endif
+#ifdef PP_NO_BP
+#define PP_K_BP(X) ""
+#else
+#define PP_K_BP(X) X
+#endif
 #ifdef PP_LATE_R   /* experiment: fetch the halo groups three steps later */
 #define PP_RA(X) ""
 #define PP_RB(X) X
@@ -470,47 +496,47 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
 #endif
 #define PP_BLOCK(KB, SP3, S0, S1, S2, S3, C0, C1, C2, C3, NB, PF, O0, O1, O2, O3, H3, HN0, HN1, HN2, LA, LB, BPF)  \
     "s_waitcnt lgkmcnt(" LA ")\n\t"                   /* Rc and this block's groups 0, 1 */     \
-    "v_readfirstlane_b32 s85, v86\n\t"                                                       \
+    PP_K_CHK("v_readfirstlane_b32 s85, v86\n\t"                                              \
     "s_add_i32 s83, s83, 16\n\t"                                                             \
     "s_min_i32 s86, s83, %[k2]\n\t"                                                          \
     "s_cmp_ge_i32 s85, s86\n\t"                                                              \
-    "s_cbranch_scc0 Lslow" #KB "_%=\n"                                                       \
+    "s_cbranch_scc0 Lslow" #KB "_%=\n")                                                      \
     "Lgo" #KB "_%=:\n\t"                                                                     \
-    "s_waitcnt vmcnt(14)\n\t"                                                                \
+    PP_K_CODE("s_waitcnt vmcnt(14)\n\t"                                                      \
     "global_load_dwordx4 " NB ", v96, s[92:93] offset:" PF "\n\t"                            \
     "v_perm_b32 " S0 ", %[phi], %[plo], " C0 "\n\t"                                          \
     "v_perm_b32 " S1 ", %[phi], %[plo], " C1 "\n\t"                                          \
     "v_perm_b32 " S2 ", %[phi], %[plo], " C2 "\n\t"                                          \
-    "v_perm_b32 " S3 ", %[phi], %[plo], " C3 "\n\t"                                          \
+    "v_perm_b32 " S3 ", %[phi], %[plo], " C3 "\n\t")                                         \
     PP_G0A(SP3)                                                                              \
     PP_RA("ds_read_b128 v[112:115], v98 offset:" H3 "\n\t")                                  \
     PP_G0B(S0)                                                                               \
     PP_RB("ds_read_b128 v[112:115], v98 offset:" H3 "\n\t")                                  \
-    "ds_write_b128 v126, v[100:103] offset:" O0 "\n\t"                                       \
+    PP_K_RING("ds_write_b128 v126, v[100:103] offset:" O0 "\n\t")                            \
     PP_KX("buffer_store_dwordx4 v[100:103], v97, s[76:79], s75 offen offset:" O0 " sc1\n\t") \
     PP_G1A(S0)                                                                               \
-    "ds_read_b32 v86, v88\n\t"                                                               \
+    PP_K_CHK("ds_read_b32 v86, v88\n\t")                                                     \
     PP_RA("ds_read_b128 v[100:103], " HN0 "\n\t")                                            \
     PP_G1B(S1)                                                                               \
     PP_RB("ds_read_b128 v[100:103], " HN0 "\n\t")                                            \
-    "ds_write_b128 v126, v[104:107] offset:" O1 "\n\t"                                       \
+    PP_K_RING("ds_write_b128 v126, v[104:107] offset:" O1 "\n\t")                            \
     PP_KX("buffer_store_dwordx4 v[104:107], v97, s[76:79], s75 offen offset:" O1 " sc1\n\t") \
     "s_waitcnt lgkmcnt(" LB ")\n\t"                   /* this block's groups 2, 3 */            \
     PP_G2A(S1)                                                                               \
     PP_RA("ds_read_b128 v[104:107], " HN1 "\n\t")                                            \
     PP_G2B(S2)                                                                               \
     PP_RB("ds_read_b128 v[104:107], " HN1 "\n\t")                                            \
-    "ds_write_b128 v126, v[108:111] offset:" O2 "\n\t"                                       \
+    PP_K_RING("ds_write_b128 v126, v[108:111] offset:" O2 "\n\t")                            \
     PP_KX("buffer_store_dwordx4 v[108:111], v97, s[76:79], s75 offen offset:" O2 " sc1\n\t") \
-    BPF                                                                                      \
+    PP_K_BP(BPF)                                                                             \
     PP_G3A(S2)                                                                               \
     PP_RA("ds_read_b128 v[108:111], " HN2 "\n\t")                                            \
     PP_G3B(S3)                                                                               \
     PP_RB("ds_read_b128 v[108:111], " HN2 "\n\t")                                            \
-    "ds_write_b128 v126, v[112:115] offset:" O3 "\n\t"                                       \
+    PP_K_RING("ds_write_b128 v126, v[112:115] offset:" O3 "\n\t")                            \
     PP_KX("buffer_store_dwordx4 v[112:115], v97, s[76:79], s75 offen offset:" O3 " sc1\n\t") \
-    "v_add_u32 v87, 16, v87\n\t"                                                             \
-    "ds_write_b32 v91, v87\n\t"
+    PP_K_PROG("v_add_u32 v87, 16, v87\n\t"                                                   \
+    "ds_write_b32 v91, v87\n\t")
 #define PP_BPFETCH "ds_read_b128 v[80:83], v89\n\tds_read_b128 v[52:55], v89 offset:16\n\tds_read_b32 v84, v90\n\t"
 // ring back-pressure before the 32 steps that start at local step s88 + D (D = 0 / 32: operands kc/kr, kc32/kr32)
 #define PP_BPCHECK(T, KC, KR)                                                                 \
@@ -629,7 +655,7 @@ __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 w
         "s_waitcnt vmcnt(0)\n\t"
         "v_perm_b32 v63, %[phi], %[plo], v79\n"
         "Lchunk_%=:\n\t"
-        PP_BPCHECK("A", "%[kc]", "%[kr]")
+        PP_K_BP(PP_BPCHECK("A", "%[kc]", "%[kr]"))
         "v_add_u32 v126, s90, %[wbase]\n\t"
         "v_mov_b32 v98, %[hbase]\n\t"
         "v_add_u32 v98, s91, v98\n\t"
@@ -641,7 +667,7 @@ __device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 w
                  "48", "v98 offset:64", "v98 offset:80", "v98 offset:96", "4", "4", "")
         PP_BLOCK(16, "v125", "v60", "v61", "v62", "v63", "v68", "v69", "v70", "v71", "v[64:67]", "16", "64", "80", "96", "112",
                  "112", "v98 offset:128", "v98 offset:144", "v98 offset:160", "4", "4", PP_BPFETCH)
-        PP_BPCHECK("B", "%[kc32]", "%[kr32]")
+        PP_K_BP(PP_BPCHECK("B", "%[kc32]", "%[kr32]"))
         PP_BLOCK(32, "v63", "v122", "v123", "v124", "v125", "v72", "v73", "v74", "v75", "v[68:71]", "32", "128", "144", "160", "176",
                  "176", "v98 offset:192", "v98 offset:208", "v98 offset:224", "4", "4", "")
         PP_BLOCK(48, "v125", "v60", "v61", "v62", "v63", "v76", "v77", "v78", "v79", "v[72:75]", "48", "192", "208", "224", "240",

@@ -170,3 +170,139 @@ class BandPipeline:
             dist.broadcast(st, src=g)
             state = st.cpu()
         return int(state[2].item())
+
+
+# =====================================================================================================
+# Band-resident pipeline (round 2): ONE persistent launch per rank.  The halo row between two bands travels
+# as {tag, H} granules (sw_fill_band_device): rank g's kernel writes the granules of its last row strip by
+# strip and raises a per-strip flag in host-pinned memory; this module forwards finished column chunks to
+# rank g+1 (RCCL / gloo point-to-point), whose kernel -- launched at the same time -- starts each strip the
+# moment that strip's 64 granules have landed.  No launch per tile, no host synchronisation inside a band;
+# the only collective stays the one all_reduce(MAX) of the packed arg-max key.
+# =====================================================================================================
+class BandResident(BandPipeline):
+    def __init__(self, dist, rank, world, engine, a, b, scores=(3, -3, -2), nchunks=64, p_dtype=None, want_h=True,
+                 reserve_cus=16, timeout_s=120.0):
+        import torch
+        self.dist, self.rank, self.world, self.eng, self.scores = dist, rank, world, engine, scores
+        self.a, self.b = np.asarray(a, np.uint8), np.asarray(b, np.uint8)
+        self.cols, self.rows = len(self.a), len(self.b)
+        self.bands = band_bounds(self.rows, world)
+        self.lo, self.hi = self.bands[rank]
+        self.active = self.hi > self.lo
+        self.timeout_s = timeout_s
+        self.tag = 0
+        self.nccl = dist.is_initialized() and dist.get_backend() == "nccl"
+        t = torch
+        dev = f"cuda:{engine.device}"
+        S = (self.cols + 62) // 63
+        per = max(1, -(-S // max(1, nchunks)))                      # strips per forwarded chunk
+        self.chunks = [(s0, min(S, s0 + per)) for s0 in range(0, S, per)]
+        self.S = S
+        self.reserve = reserve_cus if world > 1 else 0
+        if self.active:
+            br = self.hi - self.lo
+            self.d_a, _ = engine.to_device(self.a)
+            self.d_b, _ = engine.to_device(self.b[self.lo:self.hi])
+            self.H = t.zeros((br + 1, self.cols + 1), dtype=t.int32, device=dev) if want_h else None
+            self.P = t.zeros((br + 1, self.cols + 1), dtype=p_dtype or t.int32, device=dev)
+            self.res = t.zeros(3, dtype=t.int64, device=dev)
+            self.top = t.zeros(self.cols + 1, dtype=t.int64, device=dev) if self._prev() is not None else None
+            self.bot = t.zeros(self.cols + 1, dtype=t.int64, device=dev) if self._next() is not None else None
+            self.done = t.zeros(S, dtype=t.int32).pin_memory() if self.bot is not None else None
+            self.side = t.cuda.Stream(device=dev)
+            self.tiles = self        # the distributed traceback of BandPipeline walks self.P
+            self.band_rows = br
+
+    # columns of chunk k (granule indices): strips [s0, s1) own columns 63*s0+1 .. 63*s1; column 0 rides with the first chunk
+    def _cols_of(self, k):
+        s0, s1 = self.chunks[k]
+        return (0 if s0 == 0 else 63 * s0 + 1), min(self.cols, 63 * s1) + 1
+
+    def fill(self):
+        import time
+        import torch
+        dist = self.dist
+        self.tag += 1
+        tag = self.tag
+        best_key = 0
+        if self.active:
+            prev, nxt = self._prev(), self._next()
+            recvs = []
+            stage = []
+            if prev is not None and self.nccl:   # post every receive up front: the data is its own flag for the kernel
+                for k in range(len(self.chunks)):
+                    c0, c1 = self._cols_of(k)
+                    recvs.append(dist.irecv(self.top[c0:c1], src=prev))
+            self.eng.fill_band(self.d_a, self.cols, self.d_b, self.band_rows, self.rows, self.H, self.P, self.res,
+                               top_gran=self.top, top_tag=tag if self.top is not None else 0, bot_gran=self.bot,
+                               bot_tag=tag if self.bot is not None else 0, bot_done=self.done, reserve_cus=self.reserve, scores=self.scores)
+            deadline = time.time() + self.timeout_s
+            sends = []
+            flags = self.done.numpy() if self.done is not None else None
+            nk = len(self.chunks)
+            ks, kr = 0, 0          # next chunk to send / to receive (gloo: blocking receives interleaved with the sends)
+            while (nxt is not None and ks < nk) or (prev is not None and not self.nccl and kr < nk):
+                progressed = False
+                if prev is not None and not self.nccl and kr < nk:
+                    c0, c1 = self._cols_of(kr)
+                    buf = torch.empty(c1 - c0, dtype=torch.int64)
+                    dist.recv(buf, src=prev)     # ranks are chained: the sender forwards chunks in order
+                    with torch.cuda.stream(self.side):
+                        self.top[c0:c1].copy_(buf, non_blocking=False)
+                    kr += 1
+                    progressed = True
+                if nxt is not None and ks < nk:
+                    s0, s1 = self.chunks[ks]
+                    if bool((flags[s0:s1] == tag).all()):
+                        c0, c1 = self._cols_of(ks)
+                        if self.nccl:
+                            sends.append(dist.isend(self.bot[c0:c1], dst=nxt))
+                        else:
+                            with torch.cuda.stream(self.side):
+                                buf = self.bot[c0:c1].to("cpu")
+                            sends.append(dist.isend(buf, dst=nxt))
+                            stage.append(buf)
+                        ks += 1
+                        progressed = True
+                if not progressed and time.time() > deadline:
+                    raise RuntimeError(f"rank {self.rank}: band pipeline stalled at chunk {ks}/{nk} (send) {kr}/{nk} (recv)")
+            for w in recvs + sends:
+                w.wait()
+            self.eng.synchronize()
+            r = self.res.cpu().tolist()
+            if r[2] < 0:
+                from . import SwError
+                raise SwError(-62, "band kernel: hand-off wait timed out")
+            if r[1] > 0:
+                row, col = divmod(r[0], self.cols + 1)
+                gidx = (self.lo + row) * (self.cols + 1) + col
+                best_key = (r[1] << 40) | (KEY_MASK - gidx)
+        import torch
+        key = torch.tensor([best_key], dtype=torch.int64)
+        if self.nccl:
+            key = key.cuda()
+        if dist.is_initialized() and self.world > 1:
+            dist.all_reduce(key, op=dist.ReduceOp.MAX)
+        k = int(key.item())
+        return (k >> 40, KEY_MASK - (k & KEY_MASK)) if k else (0, 0)
+
+    # ---- the interface BandPipeline.traceback() needs from its tile engine
+    def walk(self, pos):
+        t = self.eng.torch
+        cap = self.band_rows + self.cols + 2
+        path = t.zeros(cap, dtype=t.int64, device=self.P.device)
+        from . import lib, _check
+        _check(lib().sw_traceback_device_ex(self.eng._h, self.P.data_ptr(), self.P.element_size(), self.cols, self.band_rows, int(pos),
+                                            path.data_ptr(), cap, self.res.data_ptr(), self.eng._stream()))
+        self.eng.synchronize()
+        n = int(self.res[2].item())
+        return n, (int(path[n - 1].item()) if n else -1)
+
+    def pred_of(self, idx):
+        m = self.cols + 1
+        pr = -int(self.P.view(-1)[idx].item())
+        return idx - m - 1 if pr == 3 else idx - m if pr == 1 else idx - 1
+
+    def matrices(self):
+        return (self.H.cpu().numpy() if self.H is not None else None), self.P.cpu().numpy()
