@@ -137,6 +137,24 @@ int sw_fill_band_device(sw_ctx* ctx, const char* d_a, int64_t cols, const char* 
                         const uint64_t* d_top_gran, uint32_t top_tag, uint64_t* d_bot_gran, uint32_t bot_tag,
                         uint32_t* d_bot_done, int reserve_cus, int concurrent, sw_result* d_result, void* stream);
 
+/* ---- one matrix over several GPUs of ONE process (one process per GPU: smith-waterman_amd/multi.py) ----
+ * Row bands, one per entry of `devices` (an id may repeat: the bands then share that GPU's CUs), every band one
+ * band-resident launch, all launched at once; finished column chunks of a band's last row are forwarded to the next
+ * band with peer copies over xGMI while the kernels run.  a, b: HOST sequences.
+ *   sw_multi_create    allocates the band-local matrices (H int32 unless want_h == 0; P int32 or int8)
+ *   sw_multi_fill      one fill of the whole matrix (blocking); result: global arg-max by the serial rule
+ *   sw_multi_traceback backtrack() across the bands (negates P along the path), total path length
+ *   sw_multi_band_info device, rows (lo, hi] and device pointers of band g (band-local (hi-lo+1) x (cols+1), row 0 = halo) */
+typedef struct sw_multi sw_multi;
+int sw_multi_create(const int* devices, int ndev, const char* a, int64_t cols, const char* b, int64_t rows,
+                    int p_elem_bytes, int want_h, sw_multi** out);
+int sw_multi_fill(sw_multi* m, const sw_scores* scores, int nchunks, sw_result* result);
+int sw_multi_traceback(sw_multi* m, int64_t* path_len);
+int sw_multi_band_info(sw_multi* m, int g, int* device, int64_t* row_lo, int64_t* row_hi, void** d_H, void** d_P);
+int sw_multi_nbands(sw_multi* m);
+double sw_multi_seconds(sw_multi* m);   /* wall time of the last sw_multi_fill */
+void sw_multi_free(sw_multi* m);
+
 /* Batch of npairs independent cols x rows problems (BASELINE config 5): pair k reads a at
  * d_a + k*a_stride and b at d_b + k*b_stride (b_stride a multiple of 16), writes d_results[k] (exact arg-max in
  * every mode) and, where given, its matrices at element offset k*(rows+1)*(cols+1).  d_H and/or d_P may be NULL. */

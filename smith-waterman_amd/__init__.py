@@ -58,6 +58,13 @@ ABI = {
     "sw_batch_traceback_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "sw_fill_band_device": (_i32, [_vp, _vp, _i64, _vp, _i64, _i64, ctypes.POINTER(_Scores), _vp, _i32, _vp, _i32, _vp, _u32, _vp, _u32, _vp,
                                    _i32, _i32, _vp, _vp]),
+    "sw_multi_create": (_i32, [ctypes.POINTER(_i32), _i32, _vp, _i64, _vp, _i64, _i32, _i32, ctypes.POINTER(_vp)]),
+    "sw_multi_fill": (_i32, [_vp, ctypes.POINTER(_Scores), _i32, ctypes.POINTER(_Result)]),
+    "sw_multi_traceback": (_i32, [_vp, ctypes.POINTER(_i64)]),
+    "sw_multi_band_info": (_i32, [_vp, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_vp), ctypes.POINTER(_vp)]),
+    "sw_multi_nbands": (_i32, [_vp]),
+    "sw_multi_seconds": (ctypes.c_double, [_vp]),
+    "sw_multi_free": (None, [_vp]),
     "sw_fill_host": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result)]),
     "sw_traceback_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "sw_traceback_host": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
@@ -462,3 +469,62 @@ def smith_waterman(a, b, scores=DEFAULT_SCORES, device: int = 0, backtrack: bool
                 "max_score": r["max_score"], "path": path}
     finally:
         eng.close()
+
+
+class MultiFill:
+    """One matrix over several GPUs of this process (sw_multi_*): row bands, band-resident launches, peer-copied halos.
+    devices may repeat an id (bands then share that GPU)."""
+
+    def __init__(self, devices, a, b, p_dtype="int32", want_h=True):
+        self.a, self.b = _as_seq(a).copy(), _as_seq(b).copy()
+        self.cols, self.rows = len(self.a), len(self.b)
+        self.pbytes = 1 if str(p_dtype).endswith("int8") else 4
+        dv = (_i32 * len(devices))(*devices)
+        h = _vp()
+        _check(lib().sw_multi_create(dv, len(devices), self.a.ctypes.data, self.cols, self.b.ctypes.data, self.rows, self.pbytes, 1 if want_h else 0,
+                                     ctypes.byref(h)))
+        self._h = h
+        self.want_h = want_h
+
+    def fill(self, scores=DEFAULT_SCORES, nchunks=64):
+        sc, r = _Scores(*scores), _Result()
+        _check(lib().sw_multi_fill(self._h, ctypes.byref(sc), nchunks, ctypes.byref(r)))
+        return {"max_pos": r.max_pos, "max_score": r.max_score, "seconds": lib().sw_multi_seconds(self._h)}
+
+    def traceback(self):
+        n = _i64()
+        _check(lib().sw_multi_traceback(self._h, ctypes.byref(n)))
+        return n.value
+
+    def bands(self):
+        """[(device, lo, hi, H (numpy or None), P (numpy int32))] copied to the host."""
+        out = []
+        for g in range(lib().sw_multi_nbands(self._h)):
+            dev, lo, hi, dH, dP = _i32(), _i64(), _i64(), _vp(), _vp()
+            _check(lib().sw_multi_band_info(self._h, g, ctypes.byref(dev), ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(dH), ctypes.byref(dP)))
+            shape = (hi.value - lo.value + 1, self.cols + 1)
+            import torch
+            with torch.cuda.device(dev.value):
+                H = None
+                if self.want_h:
+                    H = np.zeros(shape, np.int32)
+                    torch.cuda.synchronize()
+                    _hip_d2h(H, dH.value)
+                P = np.zeros(shape, np.int8 if self.pbytes == 1 else np.int32)
+                _hip_d2h(P, dP.value)
+            out.append((dev.value, lo.value, hi.value, H, P.astype(np.int32)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sw_multi_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+
+def _hip_d2h(arr: np.ndarray, dptr: int):
+    import torch
+    n = arr.nbytes
+    t = torch.as_tensor(_RawDevice(dptr, (n,), "|u1", None), device="cuda")
+    arr.view(np.uint8).reshape(-1)[:] = t.cpu().numpy()

@@ -3,6 +3,7 @@
 //   smithW <cols> <rows>    random DNA pair from the reference generator (seed 1 == serial_smithW.c)
 //   smithW --fasta A.fa B.fa   real sequences: a = first record of A.fa (columns), b = first record of B.fa (rows)
 // Extra flags (after the positional ones): --seed N  --dump  --h64  --no-backtrack  --scores M X G  --record-a I  --record-b J
+//   --gpus N | --devices 0,1,..   ONE matrix over several GPUs (row bands, sw_multi_*; an id may repeat)  --p8  int8 P
 // The DP fill runs on the GPU through the C-ABI (include/swhip.h); stdout keeps the two
 // "Elapsed time ..." lines the reference's run scripts grep for (readme.liao:12).
 #include <chrono>
@@ -48,7 +49,8 @@ static void print_pred(const std::vector<int32_t>& P, long long n, long long m) 
 
 int main(int argc, char** argv) {
     long long cols = 8, rows = 9;
-    bool builtin = true, dump = false, h64 = false, backtrack = true;
+    bool builtin = true, dump = false, h64 = false, backtrack = true, p8 = false;
+    std::vector<int> devices;
     unsigned seed = 1;
     const char *fasta_a = nullptr, *fasta_b = nullptr;
     long long rec_a = 0, rec_b = 0;
@@ -65,12 +67,15 @@ int main(int argc, char** argv) {
         if (f == "--dump") dump = true;
         else if (f == "--h64") h64 = true;
         else if (f == "--no-backtrack") backtrack = false;
+        else if (f == "--p8") p8 = true;
+        else if (f == "--gpus" && ai + 1 < argc) { const int n = atoi(argv[++ai]); for (int g = 0; g < n; ++g) devices.push_back(g); }
+        else if (f == "--devices" && ai + 1 < argc) { for (char* t = strtok(argv[++ai], ","); t; t = strtok(nullptr, ",")) devices.push_back(atoi(t)); }
         else if (f == "--fasta" && ai + 2 < argc) { fasta_a = argv[++ai]; fasta_b = argv[++ai]; builtin = false; }
         else if (f == "--record-a" && ai + 1 < argc) rec_a = strtoll(argv[++ai], nullptr, 10);
         else if (f == "--record-b" && ai + 1 < argc) rec_b = strtoll(argv[++ai], nullptr, 10);
         else if (f == "--seed" && ai + 1 < argc) seed = (unsigned)strtoul(argv[++ai], nullptr, 10);
         else if (f == "--scores" && ai + 3 < argc) { sc.match = atoi(argv[++ai]); sc.mismatch = atoi(argv[++ai]); sc.gap = atoi(argv[++ai]); }
-        else { fprintf(stderr, "usage: smithW [<cols> <rows> | --fasta A.fa B.fa [--record-a I] [--record-b J]] [--seed N] [--dump] [--h64] [--no-backtrack] [--scores M X G]\n"); return 2; }
+        else { fprintf(stderr, "usage: smithW [<cols> <rows> | --fasta A.fa B.fa [--record-a I] [--record-b J]] [--seed N] [--dump] [--h64] [--no-backtrack] [--scores M X G] [--gpus N | --devices 0,1,..] [--p8]\n"); return 2; }
     }
     if (fasta_a) {
         int64_t la = 0, lb = 0;
@@ -88,6 +93,23 @@ int main(int argc, char** argv) {
     else CHECK(sw_generate(cols, rows, seed, a.data(), b.data()));
     if (dump) { if (builtin) printf("\n Using built-in data for testing .."); printf("\nMatrix[%lld][%lld]\n", rows, cols); }
 
+    if (!devices.empty()) {
+        // ---- one matrix over several GPUs: row bands, one band-resident launch per GPU, halo rows relayed over xGMI ----
+        sw_multi* mh = nullptr;
+        CHECK(sw_multi_create(devices.data(), (int)devices.size(), a.data(), cols, b.data(), rows, p8 ? 1 : 4, 1, &mh));
+        sw_result res;
+        CHECK(sw_multi_fill(mh, &sc, 64, &res));    // untimed: sizes the workspaces
+        CHECK(sw_multi_fill(mh, &sc, 64, &res));
+        printf("\nElapsed time for scoring matrix computation: %f\n\n", sw_multi_seconds(mh));
+        double t0 = now_s();
+        int64_t plen = 0;
+        if (backtrack) CHECK(sw_multi_traceback(mh, &plen));
+        printf("\nElapsed time for backtracking: %f\n\n", now_s() - t0);
+        printf("maxPos = %lld, H[maxPos] = %lld, path length = %lld  (%d row bands)\n", (long long)res.max_pos, (long long)res.max_score,
+               (long long)plen, sw_multi_nbands(mh));
+        sw_multi_free(mh);
+        return 0;
+    }
     sw_ctx* ctx = nullptr;
     CHECK(sw_create(0, &ctx));
     const size_t cells = (size_t)m * (size_t)n;

@@ -1,0 +1,282 @@
+// sw_multi.hip -- ONE DP matrix over several GPUs of one process, behind the C-ABI.
+//
+// The reference has no multi-GPU code (its only hint is "consider atomicCAS_system for multi GPU systems",
+// simple-cuda/sw-default-discrete.cu:280).  Decomposition: contiguous ROW BANDS, one per device; every band is ONE
+// band-resident launch (sw_fill_band_device), all launched at once.  The last row of band g leaves its kernel as
+// {tag, H} granules plus a per-strip flag in host-pinned memory; a relay loop on the calling thread forwards finished
+// column chunks with hipMemcpyPeerAsync into the granule buffer band g+1's kernel is polling (xGMI peer copies: no CU of
+// either GPU is needed for the transfer), so a band's strips start the moment their halo lands.  The global arg-max is
+// the maximum of the per-band packed keys; the traceback hops from band to band at the halo rows.
+// (One process per GPU over RCCL: smith-waterman_amd/multi.py drives the same band entry point.)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "sw_kernels.h"
+
+namespace swh { void set_err(const char* fmt, ...); }
+using swh::set_err;
+
+#define HIP_TRYM(expr)                                                                \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SW_EDEVICE;                                                        \
+        }                                                                             \
+    } while (0)
+
+struct sw_multi_band {
+    int device = 0;
+    sw_ctx* ctx = nullptr;
+    int64_t lo = 0, hi = 0;            // global rows lo+1 .. hi
+    char *d_a = nullptr, *d_b = nullptr;
+    void *d_H = nullptr, *d_P = nullptr;
+    uint64_t *d_top = nullptr, *d_bot = nullptr;
+    bool host_gran = false;            // granule buffers in host-pinned memory (bands sharing one GPU: see sw_multi_create)
+    uint32_t* h_done = nullptr;        // host-pinned, one flag per strip
+    sw_result* d_res = nullptr;
+    hipStream_t stream = nullptr, copy = nullptr;
+    sw_result res = {0, 0, 0};
+};
+
+struct sw_multi {
+    std::vector<sw_multi_band> bands;
+    int64_t cols = 0, rows = 0;
+    int p_elem_bytes = 4, h_elem_bytes = 4;
+    bool want_h = true;
+    uint32_t tag = 0;
+    sw_result result = {0, 0, 0};
+    double fill_seconds = 0;
+};
+
+extern "C" {
+
+void sw_multi_free(sw_multi* m) {
+    if (!m) return;
+    for (auto& b : m->bands) {
+        (void)hipSetDevice(b.device);
+        if (b.stream) (void)hipStreamDestroy(b.stream);
+        if (b.copy) (void)hipStreamDestroy(b.copy);
+        (void)hipFree(b.d_a); (void)hipFree(b.d_b); (void)hipFree(b.d_H); (void)hipFree(b.d_P);
+        if (b.host_gran) { if (b.d_top) (void)hipHostFree(b.d_top); if (b.d_bot) (void)hipHostFree(b.d_bot); }
+        else { (void)hipFree(b.d_top); (void)hipFree(b.d_bot); }
+        (void)hipFree(b.d_res);
+        if (b.h_done) (void)hipHostFree(b.h_done);
+        if (b.ctx) sw_destroy(b.ctx);
+    }
+    delete m;
+}
+
+// Bands over devices[0..ndev-1] (an id may repeat: several bands then share that GPU, each launch capped to its share of
+// the CUs -- how the relay is tested on a one-GPU box).  a, b: HOST sequences.  Allocates the band-local matrices.
+int sw_multi_create(const int* devices, int ndev, const char* a, int64_t cols, const char* b, int64_t rows, int p_elem_bytes, int want_h,
+                    sw_multi** out) {
+    if (!devices || ndev <= 0 || !out || cols <= 0 || rows <= 0 || !a || !b || (p_elem_bytes != 4 && p_elem_bytes != 1)) {
+        set_err("sw_multi_create: bad argument");
+        return SW_EINVAL;
+    }
+    sw_multi* m = new sw_multi();
+    m->cols = cols; m->rows = rows; m->p_elem_bytes = p_elem_bytes; m->want_h = want_h != 0;
+    int64_t per = (rows + ndev - 1) / ndev;
+    per = (per + 15) / 16 * 16;       // band rows start on 16-byte windows of b
+    const int64_t S = (cols + 62) / 63;
+    int rc = SW_OK;
+    for (int g = 0; g < ndev && rc == SW_OK; ++g) {
+        sw_multi_band bd;
+        bd.device = devices[g];
+        bd.lo = std::min<int64_t>((int64_t)g * per, rows);
+        bd.hi = std::min<int64_t>((int64_t)(g + 1) * per, rows);
+        m->bands.push_back(bd);
+    }
+    while (!m->bands.empty() && m->bands.back().hi == m->bands.back().lo) m->bands.pop_back();
+    const int nb = (int)m->bands.size();
+    for (int g = 0; g < nb && rc == SW_OK; ++g) {
+        sw_multi_band& bd = m->bands[g];
+        const int64_t br = bd.hi - bd.lo;
+        const size_t cells = (size_t)(br + 1) * (size_t)(cols + 1);
+        auto dev_alloc = [&](void** p, size_t n) { return hipMalloc(p, n ? n : 1) == hipSuccess; };
+        if (hipSetDevice(bd.device) != hipSuccess) { set_err("sw_multi_create: device %d not usable", bd.device); rc = SW_ENODEV; break; }
+        if ((rc = sw_create(bd.device, &bd.ctx)) != SW_OK) break;
+        // Bands that share a GPU (one-GPU test boxes) keep their granule buffers in host-pinned memory and the relay is a
+        // plain memcpy: with several persistent kernels and copy streams on ONE device, an async copy can be mapped to the
+        // hardware queue of a polling kernel and wait behind it.  Distinct GPUs: device memory + peer copies.
+        int share0 = 0;
+        for (int k = 0; k < nb; ++k) share0 += (m->bands[k].device == bd.device);
+        bd.host_gran = share0 > 1;
+        auto gran_alloc = [&](uint64_t** p) {
+            if (!bd.host_gran) return dev_alloc((void**)p, (size_t)(cols + 1) * 8);
+            if (hipHostMalloc((void**)p, (size_t)(cols + 1) * 8, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) return false;
+            memset(*p, 0, (size_t)(cols + 1) * 8);
+            return true;
+        };
+        bool ok = dev_alloc((void**)&bd.d_a, (size_t)cols + 16) && dev_alloc((void**)&bd.d_b, (size_t)br + 16) &&
+                  (!want_h || dev_alloc(&bd.d_H, cells * 4)) && dev_alloc(&bd.d_P, cells * (size_t)p_elem_bytes) &&
+                  dev_alloc((void**)&bd.d_res, sizeof(sw_result)) && (g == 0 || gran_alloc(&bd.d_top)) && (g == nb - 1 || gran_alloc(&bd.d_bot));
+        if (!ok) { (void)hipGetLastError(); set_err("sw_multi_create: band %d does not fit device %d", g, bd.device); rc = SW_ENOMEM; break; }
+        if (g < nb - 1 && hipHostMalloc((void**)&bd.h_done, (size_t)S * 4, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {
+            set_err("sw_multi_create: pinned allocation failed"); rc = SW_ENOMEM; break;
+        }
+        if (bd.h_done) memset(bd.h_done, 0, (size_t)S * 4);
+        if (hipStreamCreateWithFlags(&bd.stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&bd.copy, hipStreamNonBlocking) != hipSuccess ||
+            hipMemcpy(bd.d_a, a, (size_t)cols, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(bd.d_b, b + bd.lo, (size_t)br, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(bd.d_P, 0, (size_t)(cols + 1) * (size_t)p_elem_bytes) != hipSuccess ||   // row 0 of a band belongs to the band above: NONE stops a walk there
+            (bd.d_top && !bd.host_gran && hipMemset(bd.d_top, 0, (size_t)(cols + 1) * 8) != hipSuccess) ||
+            (bd.d_bot && !bd.host_gran && hipMemset(bd.d_bot, 0, (size_t)(cols + 1) * 8) != hipSuccess)) {
+            set_err("sw_multi_create: device setup failed"); rc = SW_EDEVICE; break;
+        }
+        // bands that share a GPU split its CUs (every workgroup of a launch must be resident)
+        int share = 0;
+        for (int k = 0; k < nb; ++k) share += (m->bands[k].device == bd.device);
+        if (share > 1) sw_set_option(bd.ctx, "max_blocks", std::max<int64_t>(8, sw_get_option(bd.ctx, "num_cus") / share - 8));
+        // peer access for the halo copies
+        for (int k = 0; k < nb; ++k)
+            if (m->bands[k].device != bd.device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, bd.device, m->bands[k].device) == hipSuccess && can) {
+                    hipError_t e = hipDeviceEnablePeerAccess(m->bands[k].device, 0);
+                    if (e != hipSuccess) (void)hipGetLastError();   // already enabled
+                }
+            }
+    }
+    if (rc != SW_OK) { sw_multi_free(m); return rc; }
+    *out = m;
+    return SW_OK;
+}
+
+// One fill of the whole matrix: every band launched at once, halo rows relayed chunk by chunk.  Blocks until done.
+int sw_multi_fill(sw_multi* m, const sw_scores* scores, int nchunks, sw_result* result) {
+    if (!m || m->bands.empty()) { set_err("sw_multi_fill: bad argument"); return SW_EINVAL; }
+    const int nb = (int)m->bands.size();
+    const int64_t cols = m->cols, S = (cols + 62) / 63;
+    if (nchunks <= 0) nchunks = 64;
+    const int64_t per = std::max<int64_t>(1, (S + nchunks - 1) / nchunks);
+    if (++m->tag == 0) m->tag = 1;
+    const uint32_t tag = m->tag;
+    const auto t0 = std::chrono::steady_clock::now();
+    // launch in band order: a band never waits for a later one, so even if a launch call blocks (the first fill sizes the
+    // per-context workspaces, and an allocation may wait for the device) the bands before it can always finish
+    for (int g = 0; g < nb; ++g) {
+        sw_multi_band& bd = m->bands[g];
+        HIP_TRYM(hipSetDevice(bd.device));
+        int share = 0;
+        for (int k = 0; k < nb; ++k) share += (m->bands[k].device == bd.device);
+        const int rc = sw_fill_band_device(bd.ctx, bd.d_a, cols, bd.d_b, bd.hi - bd.lo, m->rows, scores, bd.d_H, 4, bd.d_P, m->p_elem_bytes,
+                                           bd.d_top, bd.d_top ? tag : 0, bd.d_bot, bd.d_bot ? tag : 0, bd.h_done, 0, share > 1, bd.d_res, bd.stream);
+        if (rc != SW_OK) return rc;
+    }
+    // relay: chunk k of band g's last row goes to band g+1 as soon as all its strips have raised their flag
+    std::vector<int64_t> next(nb, 0);   // next strip to forward per band
+    bool busy = nb > 1;
+    const auto deadline = t0 + std::chrono::seconds(120);
+    while (busy) {
+        busy = false;
+        bool moved = false;
+        for (int g = 0; g + 1 < nb; ++g) {
+            sw_multi_band& src = m->bands[g];
+            sw_multi_band& dst = m->bands[g + 1];
+            while (next[g] < S) {
+                const int64_t s0 = next[g], s1 = std::min(S, s0 + per);
+                bool ready = true;
+                for (int64_t s = s0; s < s1 && ready; ++s) ready = (__atomic_load_n(&src.h_done[s], __ATOMIC_ACQUIRE) == tag);
+                if (!ready) break;
+                const int64_t c0 = (s0 == 0) ? 0 : 63 * s0 + 1, c1 = std::min<int64_t>(cols, 63 * s1) + 1;
+                HIP_TRYM(hipSetDevice(dst.device));
+                if (src.host_gran && dst.host_gran) {
+                    memcpy(dst.d_top + c0, src.d_bot + c0, (size_t)(c1 - c0) * 8);   // both in host-pinned memory
+                    __atomic_thread_fence(__ATOMIC_RELEASE);
+                } else
+                    HIP_TRYM(hipMemcpyPeerAsync(dst.d_top + c0, dst.device, src.d_bot + c0, src.device, (size_t)(c1 - c0) * 8, dst.copy));
+                next[g] = s1;
+                moved = true;
+            }
+            if (next[g] < S) busy = true;
+        }
+        if (busy && !moved && std::chrono::steady_clock::now() > deadline) { set_err("sw_multi_fill: the band pipeline stalled"); return SW_ETIMEOUT; }
+    }
+    if (getenv("SW_MULTI_DEBUG")) {
+        fprintf(stderr, "sw_multi_fill: relay done after %.3f s;", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        for (int g = 0; g + 1 < nb; ++g) fprintf(stderr, " band %d forwarded %lld/%lld strips (flag[0]=%u tag=%u);", g, (long long)next[g], (long long)S, m->bands[g].h_done[0], tag);
+        fprintf(stderr, "\n");
+    }
+    uint64_t best = 0;
+    for (int g = 0; g < nb; ++g) {
+        sw_multi_band& bd = m->bands[g];
+        HIP_TRYM(hipSetDevice(bd.device));
+        HIP_TRYM(hipStreamSynchronize(bd.copy));
+        HIP_TRYM(hipStreamSynchronize(bd.stream));
+        HIP_TRYM(hipMemcpy(&bd.res, bd.d_res, sizeof(sw_result), hipMemcpyDeviceToHost));
+        if (bd.res.path_len < 0) { set_err("sw_multi_fill: band %d: hand-off wait timed out", g); return SW_ETIMEOUT; }
+        if (bd.res.max_score > 0) {
+            const int64_t row = bd.res.max_pos / (cols + 1), col = bd.res.max_pos % (cols + 1);
+            const uint64_t gidx = (uint64_t)(bd.lo + row) * (uint64_t)(cols + 1) + (uint64_t)col;
+            best = std::max<uint64_t>(best, ((uint64_t)bd.res.max_score << 40) | (uint64_t)(swk::SW_KEY_IDX_MASK - gidx));   // serial_smithW.c:240-242
+        }
+    }
+    m->fill_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    m->result.max_score = (int64_t)(best >> 40);
+    m->result.max_pos = best ? (int64_t)(swk::SW_KEY_IDX_MASK - (best & swk::SW_KEY_IDX_MASK)) : 0;
+    m->result.path_len = 0;
+    if (result) *result = m->result;
+    return SW_OK;
+}
+
+// backtrack() (serial_smithW.c:262-277) across the bands: the band holding max_pos walks first; when the walk reaches a
+// band's halo row the band above takes over at its last row.  Negates P along the path; returns the total length.
+int sw_multi_traceback(sw_multi* m, int64_t* path_len) {
+    if (!m || m->bands.empty()) { set_err("sw_multi_traceback: bad argument"); return SW_EINVAL; }
+    const int64_t M = m->cols + 1;
+    int64_t row = m->result.max_pos / M, col = m->result.max_pos % M, total = 0;
+    bool walking = m->result.max_score > 0;
+    for (int g = (int)m->bands.size() - 1; g >= 0 && walking; --g) {
+        sw_multi_band& bd = m->bands[g];
+        if (!(bd.lo < row && row <= bd.hi)) continue;
+        HIP_TRYM(hipSetDevice(bd.device));
+        const int64_t cap = (bd.hi - bd.lo) + m->cols + 2;
+        int64_t* d_path = nullptr;
+        HIP_TRYM(hipMalloc((void**)&d_path, (size_t)cap * 8));
+        int rc = sw_traceback_device_ex(bd.ctx, bd.d_P, m->p_elem_bytes, m->cols, bd.hi - bd.lo, (row - bd.lo) * M + col, d_path, cap, bd.d_res, bd.stream);
+        sw_result r = {0, 0, 0};
+        int64_t last = -1;
+        if (rc == SW_OK && hipStreamSynchronize(bd.stream) == hipSuccess && hipMemcpy(&r, bd.d_res, sizeof r, hipMemcpyDeviceToHost) == hipSuccess &&
+            r.path_len > 0)
+            (void)hipMemcpy(&last, d_path + (r.path_len - 1), 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d_path);
+        if (rc != SW_OK) return rc;
+        walking = false;
+        if (r.path_len > 0) {
+            total += r.path_len;
+            // where the last negated cell points
+            int32_t code4 = 0; signed char code1 = 0;
+            if (m->p_elem_bytes == 4) HIP_TRYM(hipMemcpy(&code4, (int32_t*)bd.d_P + last, 4, hipMemcpyDeviceToHost));
+            else { HIP_TRYM(hipMemcpy(&code1, (signed char*)bd.d_P + last, 1, hipMemcpyDeviceToHost)); code4 = code1; }
+            const int pr = -code4;
+            const int64_t nxt = (pr == SW_DIAGONAL) ? last - M - 1 : (pr == SW_UP) ? last - M : last - 1;
+            const int64_t r2 = nxt / M, c2 = nxt % M;
+            if (r2 == 0 && bd.lo > 0) { row = bd.lo; col = c2; walking = true; }   // crossed into the band above
+        }
+    }
+    m->result.path_len = total;
+    if (path_len) *path_len = total;
+    return SW_OK;
+}
+
+int sw_multi_band_info(sw_multi* m, int g, int* device, int64_t* row_lo, int64_t* row_hi, void** d_H, void** d_P) {
+    if (!m || g < 0 || g >= (int)m->bands.size()) { set_err("sw_multi_band_info: bad argument"); return SW_EINVAL; }
+    const sw_multi_band& bd = m->bands[g];
+    if (device) *device = bd.device;
+    if (row_lo) *row_lo = bd.lo;
+    if (row_hi) *row_hi = bd.hi;
+    if (d_H) *d_H = bd.d_H;
+    if (d_P) *d_P = bd.d_P;
+    return SW_OK;
+}
+
+int sw_multi_nbands(sw_multi* m) { return m ? (int)m->bands.size() : 0; }
+double sw_multi_seconds(sw_multi* m) { return m ? m->fill_seconds : 0.0; }
+
+}  // extern "C"

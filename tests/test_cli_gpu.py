@@ -77,3 +77,13 @@ def test_fasta_input_matches_oracle(oracle, tmp_path):
     assert H.shape == (len(b) + 1, len(a) + 1) and np.array_equal(H, oH)
     assert f"maxPos = {mp}, H[maxPos] = {int(oH.flat[mp])}" in r.stdout or str(mp) in r.stdout
     assert run("--fasta", str(fa), str(tmp_path / "nope.fa")).returncode != 0
+
+
+def test_multi_gpu_flag_two_bands_on_one_gpu(oracle):
+    """smithW --devices 0,0: the multi-GPU path of the host program (sw_multi_*), two row bands sharing the test box's GPU."""
+    r = run("3000", "1100", "--devices", "0,0")
+    assert r.returncode == 0, r.stderr
+    a, b = oracle.generate(3000, 1100, 1)
+    H, P, mp = oracle.fill(a, b)
+    path = oracle.backtrack(P, mp)
+    assert f"maxPos = {mp}, H[maxPos] = {int(H.flat[mp])}, path length = {len(path)}" in r.stdout and "(2 row bands)" in r.stdout
