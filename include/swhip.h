@@ -175,6 +175,16 @@ int sw_batch_traceback_device(sw_ctx* ctx, void* d_P, int p_elem_bytes, int64_t 
 int sw_fill_host(sw_ctx* ctx, const char* a, int64_t cols, const char* b, int64_t rows,
                  const sw_scores* scores, int32_t* H, int32_t* P, sw_result* result);
 
+/* Adaptive dispatch (the reference's per-diagonal choice of serial / OpenMP / offload,
+ * omp_smithW-v7-adaptive.cpp:304-396): tiny problems are filled on the host by sw_fill_cpu (the reference recurrence,
+ * serial_smithW.c:141-145,187-244), everything else on ctx's GPU (ctx may be NULL: host only); the traceback runs on
+ * the host P either way, so H, P, max_pos, max_score and path_len come back exactly as serial_smithW leaves them.
+ * used_gpu (optional) reports the choice. */
+int sw_align_auto(sw_ctx* ctx, const char* a, int64_t cols, const char* b, int64_t rows, const sw_scores* scores,
+                  int32_t* H, int32_t* P, sw_result* result, int* used_gpu);
+int sw_fill_cpu(const char* a, int64_t cols, const char* b, int64_t rows, const sw_scores* scores, int32_t* H, int32_t* P,
+                sw_result* result);
+
 /* ---- traceback: replaces backtrack(), serial_smithW.c:262-277.  Negates P along the path.
  * d_path (optional) receives the visited linear indices (capacity path_cap);
  * d_result->path_len is set.  P[max_pos]==NONE (UB in the reference) == empty path. */

@@ -65,6 +65,8 @@ ABI = {
     "sw_multi_nbands": (_i32, [_vp]),
     "sw_multi_seconds": (ctypes.c_double, [_vp]),
     "sw_multi_free": (None, [_vp]),
+    "sw_align_auto": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result), ctypes.POINTER(_i32)]),
+    "sw_fill_cpu": (_i32, [_vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result)]),
     "sw_fill_host": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result)]),
     "sw_traceback_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "sw_traceback_host": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, ctypes.POINTER(_i64)]),
@@ -528,3 +530,15 @@ def _hip_d2h(arr: np.ndarray, dptr: int):
     n = arr.nbytes
     t = torch.as_tensor(_RawDevice(dptr, (n,), "|u1", None), device="cuda")
     arr.view(np.uint8).reshape(-1)[:] = t.cpu().numpy()
+
+
+def align_auto(a, b, scores=DEFAULT_SCORES, engine: "Engine | None" = None):
+    """sw_align_auto: host fill for tiny problems, the GPU of `engine` otherwise; host traceback.  Returns dict like smith_waterman()."""
+    a, b = _as_seq(a).copy(), _as_seq(b).copy()
+    cols, rows = len(a), len(b)
+    H = np.zeros((rows + 1, cols + 1), np.int32)
+    P = np.zeros((rows + 1, cols + 1), np.int32)
+    sc, r, used = _Scores(*scores), _Result(), _i32()
+    _check(lib().sw_align_auto(engine._h if engine is not None else None, a.ctypes.data, cols, b.ctypes.data, rows, ctypes.byref(sc),
+                               H.ctypes.data, P.ctypes.data, ctypes.byref(r), ctypes.byref(used)))
+    return {"H": H, "P": P, "max_pos": r.max_pos, "max_score": r.max_score, "path_len": r.path_len, "used_gpu": bool(used.value)}

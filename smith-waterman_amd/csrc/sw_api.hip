@@ -549,6 +549,23 @@ int sw_fill_host(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t 
     return rc;
 }
 
+// Adaptive dispatch in the spirit of omp_smithW-v7-adaptive.cpp:304-396 (serial / OpenMP / offload chosen per diagonal by
+// its length): here the whole problem is sized once.  Below `SW_AUTO_CPU_CELLS` cells the host fill (sw_fill_cpu) wins
+// against launch + transfer latency; everything else goes to the GPU of `ctx`.  (Several GPUs: sw_multi_*, the caller
+// decides -- a single pair only scales once it is HBM-bound, about 65536^2 and up.)  path_len is set by the traceback.
+int sw_align_auto(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t rows, const sw_scores* scores, int32_t* H, int32_t* P,
+                  sw_result* result, int* used_gpu) {
+    if (!result || !H || !P) { set_err("sw_align_auto: bad argument"); return SW_EINVAL; }
+    const bool gpu = c && (double)cols * (double)rows >= 2.0e5;   // measured: a 512 x 512 host fill takes ~1.3 ms, launch + copies ~0.3 ms
+    if (used_gpu) *used_gpu = gpu ? 1 : 0;
+    int rc = gpu ? sw_fill_host(c, a, cols, b, rows, scores, H, P, result) : sw_fill_cpu(a, cols, b, rows, scores, H, P, result);
+    if (rc != SW_OK) return rc;
+    int64_t n = 0;
+    rc = sw_traceback_host(P, cols, rows, result->max_pos, nullptr, 0, &n);
+    result->path_len = n;
+    return rc;
+}
+
 int sw_traceback_device_ex(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path,
                            int64_t path_cap, sw_result* d_result, void* stream_) {
     if (!c || !d_P || !d_result || cols < 0 || rows < 0 || max_pos < 0 || max_pos >= (cols + 1) * (rows + 1) ||

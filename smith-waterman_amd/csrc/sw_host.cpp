@@ -107,6 +107,33 @@ int sw_traceback_host(int32_t* P, int64_t cols, int64_t rows, int64_t max_pos, i
     return sw_traceback_host_ex(P, 4, cols, rows, max_pos, path, path_cap, path_len);
 }
 
+// Host fill for problems too small to be worth a launch (sw_align_auto): the reference recurrence itself, row-major
+// (serial_smithW.c:141-145, 187-244).  Product code -- the oracle under oracle/ is test infrastructure and is never used here.
+int sw_fill_cpu(const char* a, int64_t cols, const char* b, int64_t rows, const sw_scores* scores, int32_t* H, int32_t* P, sw_result* result) {
+    static const sw_scores kDefault = {3, -3, -2};
+    const sw_scores* sc = scores ? scores : &kDefault;
+    if (cols < 0 || rows < 0 || !H || !P || !result || (cols > 0 && !a) || (rows > 0 && !b)) { swh::set_err("sw_fill_cpu: bad argument"); return SW_EINVAL; }
+    const int64_t m = cols + 1;
+    int64_t best_pos = 0; int32_t best = 0;
+    for (int64_t j = 0; j < m; ++j) { H[j] = 0; P[j] = 0; }
+    for (int64_t i = 1; i <= rows; ++i) {
+        int32_t* h = H + i * m; const int32_t* hu = h - m; int32_t* p = P + i * m;
+        h[0] = 0; p[0] = 0;
+        const char bi = b[i - 1];
+        for (int64_t j = 1; j < m; ++j) {
+            const int32_t diag = hu[j - 1] + (a[j - 1] == bi ? sc->match : sc->mismatch), up = hu[j] + sc->gap, left = h[j - 1] + sc->gap;
+            int32_t mx = 0, pr = SW_NONE;
+            if (diag > mx) { mx = diag; pr = SW_DIAGONAL; }
+            if (up > mx) { mx = up; pr = SW_UP; }
+            if (left > mx) { mx = left; pr = SW_LEFT; }
+            h[j] = mx; p[j] = pr;
+            if (mx > best) { best = mx; best_pos = i * m + j; }
+        }
+    }
+    result->max_pos = best_pos; result->max_score = best; result->path_len = 0;
+    return SW_OK;
+}
+
 // FASTA reader: the step before the path when the input is a real sequence instead of generate()
 // (SURVEY.md 8f-1).  '>' starts a record, ';' lines are comments, white space is dropped, letters are
 // upper-cased; a file without any '>' line is one record.

@@ -946,6 +946,10 @@ __device__ __forceinline__ void consumer_block16_h64(const u32 (&g)[SY_U + 1], u
     "v_and_b32 v98, %[rmask], v98\n\t"                                                        \
     "v_lshl_add_u32 v98, v98, 2, %[lanebase]\n\t"                                             \
     "ds_read_b32 v" #K ", v98\n\t"
+#define CL_ROW(HK, K)                                                                         \
+    "v_cmp_eq_i32 s[60:61], v" #HK ", v97\n\t"                                                \
+    "s_nop 1\n\t"                                                                             \
+    "v_cndmask_b32_e64 v99, v99, " #K ", s[60:61]\n\t"
 #define CL_ASM(POL, PST)                                                                      \
     asm volatile(                                                                             \
         "s_mov_b32 %[status], 0\n\t"                                                          \
@@ -1002,12 +1006,28 @@ __device__ __forceinline__ void consumer_block16_h64(const u32 (&g)[SY_U + 1], u
         CB_GROUPx(POL, PST, "s77", "v84", "v85", "v86", "v87", "v88", "v104", "v105", "v106", "v107", "s[48:51]") \
         CB_GROUPx(POL, PST, "s78", "v88", "v89", "v90", "v91", "v92", "v108", "v109", "v110", "v111", "s[48:51]") \
         CB_GROUPx(POL, PST, "s79", "v92", "v93", "v94", "v95", "v96", "v112", "v113", "v114", "v115", "s[48:51]") \
-        /* arg-max: the first of my blocks that reached the best value of my column (the row is re-read at the end) */ \
+        /* arg-max: the first of my blocks that reached the best value of my column.  With H in HBM the row is re-read at the  \
+           end (rr != 0); without it the lowest row holding the block maximum is taken from the H registers right here, in  \
+           the lanes that improved (the block index operand then carries the ROW) */                                         \
         "v_cmp_gt_i32 vcc, v97, %[bestv]\n\t"                                                 \
         "v_mov_b32 v98, s54\n\t"                                                              \
-        "s_nop 0\n\t"                                                                         \
+        "s_cmp_lg_u32 %[rr], 0\n\t"                                                           \
+        "s_cbranch_scc1 Lcl_upd_%=\n\t"                                                       \
+        "s_cbranch_vccz Lcl_pub_%=\n\t"                                                       \
+        "s_mov_b64 s[62:63], vcc\n\t"                                                         \
+        "v_mov_b32 v99, 15\n\t"                                                               \
+        CL_ROW(114, 14) CL_ROW(113, 13) CL_ROW(112, 12) CL_ROW(111, 11) CL_ROW(110, 10) CL_ROW(109, 9) CL_ROW(108, 8) CL_ROW(107, 7)        \
+        CL_ROW(106, 6) CL_ROW(105, 5) CL_ROW(104, 4) CL_ROW(103, 3) CL_ROW(102, 2) CL_ROW(101, 1) CL_ROW(100, 0)                          \
+        "s_lshl_b32 s56, s54, 4\n\t"                                                          \
+        "s_add_i32 s56, s56, 1\n\t"                                                           \
+        "v_add_u32 v98, s56, v99\n\t"               /* row = 16 q + 1 + k */                  \
+        "s_mov_b64 vcc, s[62:63]\n\t"                                                         \
+        "s_nop 1\n"                                                                            \
+        "Lcl_upd_%=:\n\t"                                                                     \
         "v_cndmask_b32 %[bestv], %[bestv], v97, vcc\n\t"                                      \
-        "v_cndmask_b32 %[bestblk], %[bestblk], v98, vcc\n\t"                                  \
+        "v_cndmask_b32 %[bestblk], %[bestblk], v98, vcc\n"                                     \
+        "Lcl_pub_%=:\n\t"                                                                     \
+        "v_mov_b32 v98, s54\n\t"                                                              \
         "ds_write_b32 %[slotaddr], v98\n\t"        /* in LDS order behind this block's ring reads */ \
         "v_add_u32 %[z], %[z], %[zstep]\n\t"                                                  \
         "v_add_u32 %[E], %[E], %[estep]\n\t"                                                  \
@@ -1029,7 +1049,7 @@ __device__ __forceinline__ void consumer_block16_h64(const u32 (&g)[SY_U + 1], u
           [h0] "s"(rH.x), [h1] "s"(rH.y), [h2] "s"(rH.z), [h3] "s"(rH.w), [p0] "s"(rP.x), [p1] "s"(rP.y), [p2] "s"(rP.z), [p3] "s"(rP.w),     \
           [cptr] "s"(chars), [q0] "s"(q0), [need0] "s"(need0), [es0] "s"(es0), [srmask] "s"((int)rmask), [nowrap] "s"(nowrap),               \
           [sestep] "s"((int)estep), [bh0] "s"(bh0), [bh1] "s"(bh1), [bp0] "s"(bp0), [bp1] "s"(bp1), [qstep] "s"(qstep), [qend] "s"(qend),     \
-          [stride] "s"(stride), [strideH] "s"(strideH)                                                                                     \
+          [stride] "s"(stride), [strideH] "s"(strideH), [rr] "s"(rr)                                                                       \
         : "vcc", "scc", "memory", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s58", "s59", "s60", \
           "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79",   \
           "s80", "s81", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96",   \
@@ -1040,7 +1060,7 @@ template <bool NT, bool P8>
 __device__ __forceinline__ int consumer_loop32(u32& z, u32& E, u32& bestv, u32& bestblk, u32 lanebase, u32 a_l, u32 mm_v, u32 xm_v, u32 ngap_v,
                                                u32 voff, u32 voffH, u32 zstep, u32 estep, u32 rmask, sw_i32x4 rH, sw_i32x4 rP, uint64_t blkH,
                                                uint64_t blkP, u32 stride, u32 strideH, const unsigned char* chars, u32 prod_addr, u32 slot_addr,
-                                               int q0, int qend, int qstep, int need0, int es0) {
+                                               int q0, int qend, int qstep, int need0, int es0, int rr) {
     int status;
     const int nowrap = (int)rmask + 1 - 63 - SY_U;   // ring entry (lane 0) below which no lane's 17 entries wrap
     const int bh0 = (int)(u32)blkH, bh1 = (int)(u32)(blkH >> 32), bp0 = (int)(u32)blkP, bp1 = (int)(u32)(blkP >> 32);
@@ -1384,14 +1404,14 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                 bool looped = false;
                 for (int q = ci; q < nblk; q += NC) {
                     if constexpr (sizeof(HT) == 4) {
-                        if (!looped && q > 0 && q < nblk - 1 && reread && !right_strip && !(p.debug_flags & (128 | 256))) {
+                        if (!looped && q > 0 && q < nblk - 1 && !right_strip && !(p.debug_flags & (128 | 256))) {
                             looped = true;
                             const int qs = __builtin_amdgcn_readfirstlane(q);   // (wave-uniform by construction; say so)
                             const int nmine = (nblk - 1 - qs + NC - 1) / NC;    // my blocks below the last one
                             const int qend = qs + nmine * NC;
                             const int r0 = qs * SY_U + 1;
                             u32 z = (u32)(cz + ngap * (r0 - 1)), E = (u32)(r0 - 2 + lane + phi);
-                            u32 bv = (u32)bestv, bb = (u32)bestblk;
+                            u32 bv = (u32)bestv, bb = (u32)(reread ? bestblk : bestrow);
                             const uint64_t bH = (uint64_t)(uintptr_t)(H + (int64_t)r0 * M);
                             const uint64_t bP = (uint64_t)(uintptr_t)(p8 ? (char*)P + (int64_t)r0 * M : (char*)(P + (int64_t)r0 * M));
                             const sw_i32x4 dH = {(int)(u32)bH, (int)(u32)(bH >> 32), 0x7FFFFF00, 0x00020000};
@@ -1404,7 +1424,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
 #define SW_CLOOP(NTV, P8V)                                                                                                              \
     st = consumer_loop32<NTV, P8V>(z, E, bv, bb, lanebase, a_lu, mm_v, xm_v, ngap_v, voffP, voffH, zstep, (u32)(SY_U * NC), (u32)(SY_R - 1), dH, \
                                    dP, blkH, blkP, rowP, rowH, seq_b + (r0 - 1), (u32)(size_t)&lds.prod_u[ls],                            \
-                                   (u32)(size_t)&lds.cons_blk[ls][slot], qs, qend, NC, r0 + SY_U - 1 + SY_W + phi, r0 - 2 + phi)
+                                   (u32)(size_t)&lds.cons_blk[ls][slot], qs, qend, NC, r0 + SY_U - 1 + SY_W + phi, r0 - 2 + phi, __builtin_amdgcn_readfirstlane(reread ? 1 : 0))
                             if (p.store_nt) { if (p8) SW_CLOOP(true, true); else SW_CLOOP(true, false); }
                             else { if (p8) SW_CLOOP(false, true); else SW_CLOOP(false, false); }
 #undef SW_CLOOP
@@ -1412,7 +1432,8 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                                 __hip_atomic_store((gu32*)p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 return;
                             }
-                            bestv = (int)bv; bestblk = (int)bb;
+                            bestv = (int)bv;
+                            if (reread) bestblk = (int)bb; else { bestrow = (int)bb; wbest = 0; }   // (wbest: the glue path's shortcut restarts)
                             q = qend - NC;   // the loop's increment lands on my next block
                             continue;
                         }
@@ -1510,7 +1531,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                                 });
                                 bestrow = row;
                             }
-                            int v = bestv;
+                            int v = cell_ok ? bestv : 0;   // (pad lanes may carry block maxima from the asm loop)
                             for (int off = 32; off; off >>= 1) v = max(v, __shfl_xor(v, off));
                             wbest = __builtin_amdgcn_readfirstlane(v);
                         }

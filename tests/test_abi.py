@@ -102,3 +102,14 @@ def test_create_without_gpu_fails_loudly(swamd):
     assert rc == -19 and h.value is None
     with pytest.raises(RuntimeError):
         swamd.Engine(0)
+
+
+@pytest.mark.parametrize("name", ["kat_builtin", "rand_8x9_s1", "rand_1x1_s1", "rand_256x256_s1", "rand_300x200_s1", "rand_65x130_s7"])
+def test_align_auto_host_side_matches_reference(swamd, name):
+    """sw_align_auto without a GPU context: the host fill (sw_fill_cpu, product code -- not the oracle) + host traceback
+    reproduce the reference fixtures bit for bit: H, P after the traceback, maxPos, score, path length."""
+    g = golden(name)
+    r = swamd.align_auto(g["a"], g["b"])
+    assert not r["used_gpu"]
+    assert np.array_equal(r["H"], g["H"]) and np.array_equal(r["P"], g["P1"])
+    assert r["max_pos"] == int(g["meta"][3]) and r["max_score"] == int(g["meta"][4]) and r["path_len"] == len(g["path"])

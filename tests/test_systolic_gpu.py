@@ -182,3 +182,15 @@ def test_many_launches_of_mixed_shapes_across_the_tag_wrap(engine, swamd):
             out = engine.fill(g["a"], g["b"])
             assert np.array_equal(out.H.cpu().numpy(), g["H"]) and np.array_equal(out.P.cpu().numpy(), g["P0"]), f"iteration {it}"
             assert out.result()["max_pos"] == int(g["meta"][3])
+
+
+def test_align_auto_picks_host_or_gpu(engine, oracle, swamd):
+    """sw_align_auto (adaptive dispatch, omp_smithW-v7-adaptive.cpp:304-396): tiny problems on the host, the rest on the
+    GPU; either way the result equals serial_smithW including the negated path."""
+    for cols, rows, want_gpu in ((40, 30, False), (300, 200, False), (1200, 900, True)):
+        a, b = oracle.generate(cols, rows, 3)
+        H, P, mp = oracle.fill(a, b)
+        path = oracle.backtrack(P, mp)
+        r = swamd.align_auto(a, b, engine=engine)
+        assert r["used_gpu"] == want_gpu
+        assert np.array_equal(r["H"], H) and np.array_equal(r["P"], P) and r["max_pos"] == mp and r["path_len"] == len(path)

@@ -147,3 +147,30 @@ def test_band_pipeline_single_gpu(engine, oracle):
         assert n == len(path) and np.array_equal(dH, H) and np.array_equal(dP, P)
     finally:
         dist.destroy_process_group()
+
+
+def test_config5_at_scale_100000_pairs_sampled(engine, oracle, swamd):
+    """BASELINE config 5 at FULL scale: 100 000 pairs of 1024 x 1024 (pair k seeded 1+k) in one call, int8 P for every
+    pair (105 GB resident), per-pair traceback; 1000 sampled pairs are checked against the oracle: score, maxPos, path
+    length, and the whole (negated) P matrix for 50 of them."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < (125 << 30):
+        pytest.skip(f"needs 125 GB of free HBM, {free >> 30} GB free")
+    npairs = 100000
+    A = np.empty((npairs, 1024), np.uint8)
+    B = np.empty((npairs, 1024), np.uint8)
+    for k in range(npairs):
+        A[k], B[k] = swamd.generate(1024, 1024, 1 + k)
+    res, H, P = engine.batch(A, B, store=True, p_dtype=torch.int8, store_h=False, traceback=True)
+    res = res.cpu().numpy()
+    rng = np.random.default_rng(7)
+    sample = np.unique(np.concatenate([[0, 1, npairs - 1, 4095, 4096, 4097], rng.integers(0, npairs, 1000)]))
+    for n, k in enumerate(sample):
+        h, p, mp = oracle.fill(A[k], B[k])
+        path = oracle.backtrack(p, mp)
+        assert res[k, 0] == mp and res[k, 1] == int(h.flat[mp]) and res[k, 2] == len(path), f"pair {k}"
+        if n % 20 == 0:
+            assert np.array_equal(P[k].cpu().numpy().astype(np.int32), p), f"pair {k} P"
+    del P
+    torch.cuda.empty_cache()
