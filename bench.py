@@ -25,6 +25,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # several ranks: a band kernel stays resident while RCCL's send/recv kernels (other streams) deliver its halo.  Give every
+    # stream its own hardware queue (the HIP default of 4 lets a transfer queue up behind the band kernel), and keep
+    # RCCL's point-to-point kernels within the CUs the band launch leaves free (--reserve-cus).  Set before HIP initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("NCCL_MAX_P2P_NCHANNELS", "4")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 

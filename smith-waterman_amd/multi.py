@@ -204,8 +204,16 @@ class BandResident(BandPipeline):
             br = self.hi - self.lo
             self.d_a, _ = engine.to_device(self.a)
             self.d_b, _ = engine.to_device(self.b[self.lo:self.hi])
-            self.H = t.zeros((br + 1, self.cols + 1), dtype=t.int32, device=dev) if want_h else None
-            self.P = t.zeros((br + 1, self.cols + 1), dtype=p_dtype or t.int32, device=dev)
+            if world == 1 and want_h and (br + 1) * (self.cols + 1) * 8 <= (16 << 30):
+                # small matrix: where H and P lie in HBM matters -- take them from the C-ABI allocator
+                # (its trial fills use the whole GPU: not with several ranks, which may share one)
+                self._out, _ = engine.alloc_outputs(self.d_a, self.d_b, self.cols, br, p_dtype=p_dtype, scores=scores)
+                self.H, self.P = self._out.H, self._out.P
+                self.H[0].zero_()
+                self.P[0].zero_()
+            else:
+                self.H = t.zeros((br + 1, self.cols + 1), dtype=t.int32, device=dev) if want_h else None
+                self.P = t.zeros((br + 1, self.cols + 1), dtype=p_dtype or t.int32, device=dev)
             self.res = t.zeros(3, dtype=t.int64, device=dev)
             self.top = t.zeros(self.cols + 1, dtype=t.int64, device=dev) if self._prev() is not None else None
             self.bot = t.zeros(self.cols + 1, dtype=t.int64, device=dev) if self._next() is not None else None
@@ -213,11 +221,25 @@ class BandResident(BandPipeline):
             self.side = t.cuda.Stream(device=dev)
             self.tiles = self        # the distributed traceback of BandPipeline walks self.P
             self.band_rows = br
+        if self.nccl and world > 1:
+            # RCCL builds a communicator per rank pair at the first send/recv: do that here, down the chain, not while
+            # band kernels wait for each other
+            probe = t.zeros(2, dtype=t.int64, device=dev)
+            if self.active and self._prev() is not None:
+                dist.recv(probe, src=self._prev())
+            if self.active and self._next() is not None:
+                dist.send(probe, dst=self._next())
+            t.cuda.synchronize()
 
     # columns of chunk k (granule indices): strips [s0, s1) own columns 63*s0+1 .. 63*s1; column 0 rides with the first chunk
+    # Cut at even granule indices: every forwarded piece is then 16-byte aligned, so no transport has a reason to move a
+    # granule in pieces smaller than its 8 bytes (a granule is valid only as a whole).  A granule that is cut off rides
+    # with the next chunk; its strip is finished by then.
     def _cols_of(self, k):
         s0, s1 = self.chunks[k]
-        return (0 if s0 == 0 else 63 * s0 + 1), min(self.cols, 63 * s1) + 1
+        c0 = 0 if s0 == 0 else (63 * s0 + 1) & ~1
+        c1 = self.cols + 1 if s1 >= self.S else (63 * s1 + 1) & ~1
+        return c0, c1
 
     def fill(self):
         import time
@@ -257,7 +279,10 @@ class BandResident(BandPipeline):
                     if bool((flags[s0:s1] == tag).all()):
                         c0, c1 = self._cols_of(ks)
                         if self.nccl:
-                            sends.append(dist.isend(self.bot[c0:c1], dst=nxt))
+                            # issued from the idle side stream: the send must not be ordered behind the band kernel
+                            # that is still running on the fill stream
+                            with torch.cuda.stream(self.side):
+                                sends.append(dist.isend(self.bot[c0:c1], dst=nxt))
                         else:
                             with torch.cuda.stream(self.side):
                                 buf = self.bot[c0:c1].to("cpu")
