@@ -247,7 +247,7 @@ def run_bands(args, sw, eng, torch, dist, rank, world, local):
                                    f"{-(-rows // world)} rows, one band-resident launch per GPU, "
                                    f"{'no H' if args.no_h else 'int32 H'} + {'int8' if p8 else 'int32'} P written to HBM ({bpc} B/cell, "
                                    f"{bpc * (cols + 1) * (rows + 1) / world / 2**30:.0f} GiB per GPU), arg-max tracked, halo rows as granules over "
-                                   f"{'RCCL send/recv' if world > 1 else 'nothing (single band)'} in {len(pipe.chunks)} column chunks",
+                                   f"{('RCCL send/recv' if pipe.nccl else 'gloo send/recv (rehearsal: ranks share GPUs)') if world > 1 else 'nothing (single band)'} in {len(pipe.chunks)} column chunks",
                        "mode": "bands", "max_score": score, "max_pos": pos},
             "roofline": {"bound": "hbm", "achieved": achieved / world, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / world / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "sw_systolic", "algorithmic_bytes_per_cell": bpc, "per": "GPU (whole job / n_gpus)"}}
@@ -298,6 +298,7 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "pair", "bands", "batch", "replicas"],
                     help="auto: pair on one GPU, bands (one matrix sharded over the ranks) on several; replicas: one independent pair "
                          "per GPU; batch: --pairs independent pairs in one call (BASELINE config 5)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="several ranks: nccl (= RCCL; one GPU per rank) or gloo (rehearsal, ranks may share a GPU)")
     ap.add_argument("--chunks", type=int, default=64, help="bands: column chunks the halo row is forwarded in")
     ap.add_argument("--reserve-cus", type=int, default=16, help="bands, several GPUs: CUs left to the halo transfers")
     ap.add_argument("--p32", action="store_true", help="bands on several GPUs: int32 P instead of int8 (550 GB at 262144^2)")
@@ -323,12 +324,20 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    ndev = torch.cuda.device_count()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:   # rehearsal of the multi-rank path on a box with fewer GPUs than ranks: gloo, the ranks share GPUs
+            dist.init_process_group("gloo")
+            local = local % max(1, ndev)
     torch.cuda.set_device(local)
     sw = importlib.import_module("smith-waterman_amd")
     eng = sw.Engine(local)
+    if world > 1 and args.backend != "nccl" and ndev < world and not args.max_blocks:
+        # persistent launches of several ranks on one GPU must all be resident: split the CUs
+        args.max_blocks = max(8, eng.get_option("num_cus") // -(-world // max(1, ndev)) - 16)
     eng.set_option("engine", args.engine)
     for name, v in (("importers", args.importers), ("store_policy", args.store_policy), ("strips_per_group", args.ns), ("consumers", args.nc),
                     ("debug_flags", args.debug_flags), ("max_blocks", args.max_blocks)):

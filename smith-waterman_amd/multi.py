@@ -252,35 +252,50 @@ class BandResident(BandPipeline):
             prev, nxt = self._prev(), self._next()
             recvs = []
             stage = []
-            if prev is not None and self.nccl:   # post every receive up front: the data is its own flag for the kernel
-                for k in range(len(self.chunks)):
-                    c0, c1 = self._cols_of(k)
+            nk = len(self.chunks)
+            kr = 0                 # next chunk to receive (gloo: blocking receives interleaved with the sends)
+
+            def post_recv():
+                # RCCL: the receive lands straight in the granule buffer the kernel polls -- the data is its own flag.  Issued
+                # from the idle side stream (an op issued from the fill stream is ordered behind the running band kernel); at
+                # most two are outstanding, so that a send never queues behind a long line of receives should both directions
+                # share one RCCL stream.
+                nonlocal kr
+                c0, c1 = self._cols_of(kr)
+                with torch.cuda.stream(self.side):
                     recvs.append(dist.irecv(self.top[c0:c1], src=prev))
+                kr += 1
+
+            if prev is not None and self.nccl:
+                while kr < min(2, nk):
+                    post_recv()
             self.eng.fill_band(self.d_a, self.cols, self.d_b, self.band_rows, self.rows, self.H, self.P, self.res,
                                top_gran=self.top, top_tag=tag if self.top is not None else 0, bot_gran=self.bot,
                                bot_tag=tag if self.bot is not None else 0, bot_done=self.done, reserve_cus=self.reserve, scores=self.scores)
             deadline = time.time() + self.timeout_s
             sends = []
             flags = self.done.numpy() if self.done is not None else None
-            nk = len(self.chunks)
-            ks, kr = 0, 0          # next chunk to send / to receive (gloo: blocking receives interleaved with the sends)
-            while (nxt is not None and ks < nk) or (prev is not None and not self.nccl and kr < nk):
+            ks = 0                 # next chunk to send
+            while (nxt is not None and ks < nk) or (prev is not None and kr < nk):
                 progressed = False
-                if prev is not None and not self.nccl and kr < nk:
-                    c0, c1 = self._cols_of(kr)
-                    buf = torch.empty(c1 - c0, dtype=torch.int64)
-                    dist.recv(buf, src=prev)     # ranks are chained: the sender forwards chunks in order
-                    with torch.cuda.stream(self.side):
-                        self.top[c0:c1].copy_(buf, non_blocking=False)
-                    kr += 1
-                    progressed = True
+                if prev is not None and kr < nk:
+                    if self.nccl:
+                        if recvs[kr - 2].is_completed():
+                            post_recv()
+                            progressed = True
+                    else:
+                        c0, c1 = self._cols_of(kr)
+                        buf = torch.empty(c1 - c0, dtype=torch.int64)
+                        dist.recv(buf, src=prev)     # ranks are chained: the sender forwards chunks in order
+                        with torch.cuda.stream(self.side):
+                            self.top[c0:c1].copy_(buf, non_blocking=False)
+                        kr += 1
+                        progressed = True
                 if nxt is not None and ks < nk:
                     s0, s1 = self.chunks[ks]
                     if bool((flags[s0:s1] == tag).all()):
                         c0, c1 = self._cols_of(ks)
                         if self.nccl:
-                            # issued from the idle side stream: the send must not be ordered behind the band kernel
-                            # that is still running on the fill stream
                             with torch.cuda.stream(self.side):
                                 sends.append(dist.isend(self.bot[c0:c1], dst=nxt))
                         else:
@@ -290,7 +305,9 @@ class BandResident(BandPipeline):
                             stage.append(buf)
                         ks += 1
                         progressed = True
-                if not progressed and time.time() > deadline:
+                if progressed:
+                    deadline = time.time() + self.timeout_s
+                elif time.time() > deadline:
                     raise RuntimeError(f"rank {self.rank}: band pipeline stalled at chunk {ks}/{nk} (send) {kr}/{nk} (recv)")
             for w in recvs + sends:
                 w.wait()
