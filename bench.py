@@ -248,7 +248,8 @@ def run_bands(args, sw, eng, torch, dist, rank, world, local):
                                    f"{'no H' if args.no_h else 'int32 H'} + {'int8' if p8 else 'int32'} P written to HBM ({bpc} B/cell, "
                                    f"{bpc * (cols + 1) * (rows + 1) / world / 2**30:.0f} GiB per GPU), arg-max tracked, halo rows as granules over "
                                    f"{('RCCL send/recv' if pipe.nccl else 'gloo send/recv (rehearsal: ranks share GPUs)') if world > 1 else 'nothing (single band)'} in {len(pipe.chunks)} column chunks",
-                       "mode": "bands", "max_score": score, "max_pos": pos},
+                       "mode": "bands", "max_score": score, "max_pos": pos,
+                       "placement_trials_ms_rank0": [round(x, 3) for x in getattr(pipe, "placement_ms", [])]},
             "roofline": {"bound": "hbm", "achieved": achieved / world, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / world / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "sw_systolic", "algorithmic_bytes_per_cell": bpc, "per": "GPU (whole job / n_gpus)"}}
     print(json.dumps(line), flush=True)
@@ -314,6 +315,7 @@ def main():
                     help="pair mode: candidate H/P placements sw_alloc_outputs may try before the timed region (1 = plain allocation)")
     ap.add_argument("--store-policy", type=int, default=0, help="systolic H/P stores: 0 auto, 1 write-back, 2 streaming")
     ap.add_argument("--importers", type=int, default=0)
+    ap.add_argument("--xcd-order", type=int, default=0, help="systolic: 1 = neighbouring strip groups on one XCD")
     ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
     args = ap.parse_args()
@@ -340,7 +342,7 @@ def main():
         args.max_blocks = max(8, eng.get_option("num_cus") // -(-world // max(1, ndev)) - 16)
     eng.set_option("engine", args.engine)
     for name, v in (("importers", args.importers), ("store_policy", args.store_policy), ("strips_per_group", args.ns), ("consumers", args.nc),
-                    ("debug_flags", args.debug_flags), ("max_blocks", args.max_blocks)):
+                    ("debug_flags", args.debug_flags), ("max_blocks", args.max_blocks), ("xcd_order", args.xcd_order)):
         if v:
             eng.set_option(name, v)
     mode = args.mode

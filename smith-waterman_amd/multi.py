@@ -204,10 +204,13 @@ class BandResident(BandPipeline):
             br = self.hi - self.lo
             self.d_a, _ = engine.to_device(self.a)
             self.d_b, _ = engine.to_device(self.b[self.lo:self.hi])
-            if world == 1 and want_h and (br + 1) * (self.cols + 1) * 8 <= (16 << 30):
-                # small matrix: where H and P lie in HBM matters -- take them from the C-ABI allocator
-                # (its trial fills use the whole GPU: not with several ranks, which may share one)
-                self._out, _ = engine.alloc_outputs(self.d_a, self.d_b, self.cols, br, p_dtype=p_dtype, scores=scores)
+            self.placement_ms = []
+            if (world == 1 or self.nccl) and want_h:
+                # where H and P lie in HBM moves the fill by 15-30 %: take them from the C-ABI allocator,
+                # which tries a few placements with fills of this band.  Its trial fills use the whole GPU, so not when
+                # several ranks may share one (gloo rehearsals).
+                self._out, self.placement_ms = engine.alloc_outputs(self.d_a, self.d_b, self.cols, br, p_dtype=p_dtype, scores=scores,
+                                                                    trials=4 if (br + 1) * (self.cols + 1) > (1 << 32) else 0)
                 self.H, self.P = self._out.H, self._out.P
                 self.H[0].zero_()
                 self.P[0].zero_()
