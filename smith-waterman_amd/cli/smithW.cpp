@@ -55,16 +55,15 @@ int main(int argc, char** argv) {
     const char *fasta_a = nullptr, *fasta_b = nullptr;
     long long rec_a = 0, rec_b = 0;
     sw_scores sc = {3, -3, -2};
-    int ai = 1;
-    if (argc >= 3 && argv[1][0] != '-' && argv[2][0] != '-') {
-        cols = strtoll(argv[1], nullptr, 10);
-        rows = strtoll(argv[2], nullptr, 10);
-        builtin = false;
-        ai = 3;
-    }
-    for (; ai < argc; ++ai) {
+    int npos = 0;
+    for (int ai = 1; ai < argc; ++ai) {
         std::string f = argv[ai];
-        if (f == "--dump") dump = true;
+        if (f[0] != '-' && npos < 2 && ai + (1 - npos) < argc) {   // <cols> <rows>, anywhere on the line
+            (npos == 0 ? cols : rows) = strtoll(argv[ai], nullptr, 10);
+            builtin = false;
+            ++npos;
+        }
+        else if (f == "--dump") dump = true;
         else if (f == "--h64") h64 = true;
         else if (f == "--no-backtrack") backtrack = false;
         else if (f == "--p8") p8 = true;
@@ -77,6 +76,7 @@ int main(int argc, char** argv) {
         else if (f == "--scores" && ai + 3 < argc) { sc.match = atoi(argv[++ai]); sc.mismatch = atoi(argv[++ai]); sc.gap = atoi(argv[++ai]); }
         else { fprintf(stderr, "usage: smithW [<cols> <rows> | --fasta A.fa B.fa [--record-a I] [--record-b J]] [--seed N] [--dump] [--h64] [--no-backtrack] [--scores M X G] [--gpus N | --devices 0,1,..] [--p8]\n"); return 2; }
     }
+    if (npos == 1) { fprintf(stderr, "smithW: <cols> needs <rows>\n"); return 2; }
     if (fasta_a) {
         int64_t la = 0, lb = 0;
         CHECK(sw_read_fasta(fasta_a, rec_a, nullptr, 0, &la));

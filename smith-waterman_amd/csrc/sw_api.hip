@@ -186,23 +186,26 @@ struct FillJob {
     int64_t total_rows = 0;       // band: rows of the whole matrix (bounds the scores a halo can carry)
 };
 
-// called with g_dev[device].mu held: make `stream` wait for the fills enqueued on other streams of this device
+// called with g_dev[device].mu held: make `stream` wait for the fill enqueued last on another stream of this device.  The
+// event is recorded on a fill's OWN stream when the fill has been enqueued (DevOrder's destructor), never on the previous
+// stream later on: that stream may have been destroyed by then.
 static int order_after_previous_fill(DevState& d, hipStream_t stream, bool allow_concurrent) {
-    if (d.any && d.last_stream != stream && !allow_concurrent) {
-        if (!d.ev) HIP_TRY(hipEventCreateWithFlags(&d.ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(d.ev, d.last_stream));
-        HIP_TRY(hipStreamWaitEvent(stream, d.ev, 0));
-    }
-    d.any = true;
-    d.last_stream = stream;
+    if (d.any && d.last_stream != stream && !allow_concurrent && d.ev) HIP_TRY(hipStreamWaitEvent(stream, d.ev, 0));
     return SW_OK;
 }
 
 struct DevOrder {   // RAII: device lock + stream ordering for one fill call
     std::unique_lock<std::mutex> lk;
+    DevState& d;
+    hipStream_t stream;
     int rc;
-    DevOrder(sw_ctx* c, hipStream_t stream, bool concurrent) : lk(g_dev[c->device & 63].mu) {
-        rc = order_after_previous_fill(g_dev[c->device & 63], stream, concurrent);
+    DevOrder(sw_ctx* c, hipStream_t st, bool concurrent) : lk(g_dev[c->device & 63].mu), d(g_dev[c->device & 63]), stream(st) {
+        rc = order_after_previous_fill(d, stream, concurrent);
+    }
+    ~DevOrder() {
+        if (!d.ev && hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) { d.ev = nullptr; (void)hipGetLastError(); }
+        if (d.ev && hipEventRecord(d.ev, stream) == hipSuccess) { d.any = true; d.last_stream = stream; }
+        else { (void)hipGetLastError(); d.any = false; }
     }
 };
 

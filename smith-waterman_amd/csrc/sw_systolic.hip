@@ -494,13 +494,37 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
 #define PP_RA(X) X
 #define PP_RB(X) ""
 #endif
-#define PP_BLOCK(KB, SP3, S0, S1, S2, S3, C0, C1, C2, C3, NB, PF, O0, O1, O2, O3, H3, HN0, HN1, HN2, LA, LB, BPF)  \
-    "s_waitcnt lgkmcnt(" LA ")\n\t"                   /* Rc and this block's groups 0, 1 */     \
-    PP_K_CHK("v_readfirstlane_b32 s85, v86\n\t"                                              \
-    "s_add_i32 s83, s83, 16\n\t"                                                             \
-    "s_min_i32 s86, s83, %[k2]\n\t"                                                          \
-    "s_cmp_ge_i32 s85, s86\n\t"                                                              \
-    "s_cbranch_scc0 Lslow" #KB "_%=\n")                                                      \
+// The halo check comes in two forms (V):
+//   V = 0  progress: the left neighbour's progress counter, sampled (Rc) before the next block's groups are fetched, must
+//          have covered that whole block -- a look-ahead of 28 steps.  For a left neighbour in the same workgroup.
+//   V = 1  validate on use: the importer keeps every halo slot it has not filled yet at 0 (no G is 0: they all carry the
+//          launch bias), so a fetched group says by itself whether it was there; groups are checked in pairs (the last
+//          value of each -- the importer fills in step order) right before their first use: a look-ahead of 12 steps.
+#define PP_CHKA_0(KB)                                                                         \
+    "v_readfirstlane_b32 s85, v86\n\t"                                                        \
+    "s_add_i32 s83, s83, 16\n\t"                                                              \
+    "s_min_i32 s86, s83, %[k2]\n\t"                                                           \
+    "s_cmp_ge_i32 s85, s86\n\t"                                                               \
+    "s_cbranch_scc0 Lslow" #KB "_%=\n"
+#define PP_CHKA_1(KB)     /* both there <=> the AND keeps the tag byte: s_and sets SCC = (result != 0).  (No VALU in it: a */  \
+    "v_readfirstlane_b32 s85, v103\n\t"      /* VGPR written by a VALU op cannot be read by v_readfirstlane in the next slot) */     \
+    "v_readfirstlane_b32 s86, v107\n\t"                                                       \
+    "s_and_b32 s85, s85, s86\n\t"                                                             \
+    "s_cbranch_scc0 Lslow" #KB "_%=\n"
+#define PP_CHKB_0(KB) ""
+#define PP_CHKB_1(KB)                                                                         \
+    "v_readfirstlane_b32 s85, v111\n\t"                                                       \
+    "v_readfirstlane_b32 s86, v115\n\t"                                                       \
+    "s_and_b32 s85, s85, s86\n\t"                                                             \
+    "s_cbranch_scc0 LslowB" #KB "_%=\n"                                                        \
+    "LgoB" #KB "_%=:\n\t"
+#define PP_RC_0 "ds_read_b32 v86, v88\n\t"
+#define PP_RC_1 ""
+#define PP_LB_0 "4"
+#define PP_LB_1 "3"      /* no Rc in the queue */
+#define PP_BLOCK_(V, KB, SP3, S0, S1, S2, S3, C0, C1, C2, C3, NB, PF, O0, O1, O2, O3, H3, HN0, HN1, HN2, LA, BPF)  \
+    "s_waitcnt lgkmcnt(" LA ")\n\t"                   /* (Rc and) this block's groups 0, 1 */   \
+    PP_K_CHK(PP_CHKA_##V(KB))                                                                \
     "Lgo" #KB "_%=:\n\t"                                                                     \
     PP_K_CODE("s_waitcnt vmcnt(14)\n\t"                                                      \
     "global_load_dwordx4 " NB ", v96, s[92:93] offset:" PF "\n\t"                            \
@@ -515,13 +539,14 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
     PP_K_RING("ds_write_b128 v126, v[100:103] offset:" O0 "\n\t")                            \
     PP_KX("buffer_store_dwordx4 v[100:103], v97, s[76:79], s75 offen offset:" O0 " sc1\n\t") \
     PP_G1A(S0)                                                                               \
-    PP_K_CHK("ds_read_b32 v86, v88\n\t")                                                     \
+    PP_K_CHK(PP_RC_##V)                                                                      \
     PP_RA("ds_read_b128 v[100:103], " HN0 "\n\t")                                            \
     PP_G1B(S1)                                                                               \
     PP_RB("ds_read_b128 v[100:103], " HN0 "\n\t")                                            \
     PP_K_RING("ds_write_b128 v126, v[104:107] offset:" O1 "\n\t")                            \
     PP_KX("buffer_store_dwordx4 v[104:107], v97, s[76:79], s75 offen offset:" O1 " sc1\n\t") \
-    "s_waitcnt lgkmcnt(" LB ")\n\t"                   /* this block's groups 2, 3 */            \
+    "s_waitcnt lgkmcnt(" PP_LB_##V ")\n\t"            /* this block's groups 2, 3 */            \
+    PP_K_CHK(PP_CHKB_##V(KB))                                                                \
     PP_G2A(S1)                                                                               \
     PP_RA("ds_read_b128 v[104:107], " HN1 "\n\t")                                            \
     PP_G2B(S2)                                                                               \
@@ -577,7 +602,7 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
     "s_branch Lbpe" T "_%=\n"                                                                \
     "Lbpok" T "_%=:\n\t"
 // out-of-line: wait until the left neighbour has produced this block's halo, then fetch its first three groups
-#define PP_SLOW(KB, R0, R1, R2)                                                               \
+#define PP_SLOW_0(KB, R0, R1, R2, R3)                                                         \
     "Lslow" #KB "_%=:\n\t"                                                                   \
     "s_mov_b32 s89, 0\n"                                                                     \
     "Lpoll" #KB "_%=:\n\t"                                                                   \
@@ -600,107 +625,57 @@ __device__ __forceinline__ int producer_fast(u32 a_l, u32 xm_v, u32 mm_v, u32 ng
     "ds_read_b128 v[108:111], v98 offset:" R2 "\n\t"                                         \
     "s_waitcnt lgkmcnt(0)\n\t"                                                               \
     "s_branch Lgo" #KB "_%=\n"
+// validate on use: fetch the pair of groups again until both are there.  (Group 2 is fetched along with 0 and 1: the
+// first block of a strip has no block before it that would have done so.)
+#define PP_SLOW_1(KB, R0, R1, R2, R3)                                                         \
+    "Lslow" #KB "_%=:\n\t"                                                                   \
+    "s_mov_b32 s89, 0\n"                                                                     \
+    "Lpoll" #KB "_%=:\n\t"                                                                   \
+    "ds_read_b128 v[100:103], v98 offset:" R0 "\n\t"                                         \
+    "ds_read_b128 v[104:107], v98 offset:" R1 "\n\t"                                         \
+    "ds_read_b128 v[108:111], v98 offset:" R2 "\n\t"                                         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+    "v_readfirstlane_b32 s85, v103\n\t"                                                      \
+    "v_readfirstlane_b32 s86, v107\n\t"                                                      \
+    "s_and_b32 s85, s85, s86\n\t"                                                            \
+    "s_cbranch_scc1 Lgo" #KB "_%=\n\t"                                                       \
+    "s_add_i32 s89, s89, 1\n\t"                                                              \
+    "s_add_i32 s95, s95, 1\n\t"                                                              \
+    "s_cmp_lt_u32 s89, 0x1000000\n\t"                                                        \
+    "s_cbranch_scc1 Lpoll" #KB "_%=\n\t"                                                     \
+    "s_mov_b32 %[status], 1\n\t"                                                             \
+    "s_branch Lexit_%=\n"                                                                    \
+    "LslowB" #KB "_%=:\n\t"                                                                  \
+    "s_mov_b32 s89, 0\n"                                                                     \
+    "LpollB" #KB "_%=:\n\t"                                                                  \
+    "ds_read_b128 v[108:111], v98 offset:" R2 "\n\t"                                         \
+    "ds_read_b128 v[112:115], v98 offset:" R3 "\n\t"                                         \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                               \
+    "v_readfirstlane_b32 s85, v111\n\t"                                                      \
+    "v_readfirstlane_b32 s86, v115\n\t"                                                      \
+    "s_and_b32 s85, s85, s86\n\t"                                                            \
+    "s_cbranch_scc1 LgoB" #KB "_%=\n\t"                                                      \
+    "s_add_i32 s89, s89, 1\n\t"                                                              \
+    "s_add_i32 s95, s95, 1\n\t"                                                              \
+    "s_cmp_lt_u32 s89, 0x1000000\n\t"                                                        \
+    "s_cbranch_scc1 LpollB" #KB "_%=\n\t"                                                    \
+    "s_mov_b32 %[status], 1\n\t"                                                             \
+    "s_branch Lexit_%=\n"
 
 typedef int sw_i32x4p __attribute__((ext_vector_type(4)));
-// UT must be a multiple of 64 (the exit test sits at the end of a chunk)
-__device__ __forceinline__ int producer_perm(u32 plo, u32 phi, u32 ngap_v, u32 wbase, u32 voff, u32 z1, u32 g0, u32 tm1, u32 expoff,
-                                             const unsigned char* cbase, u32 hbase, int hoff4, u32 cnt_addr, u32 cons_addr,
-                                             u32 right_addr, u32 prog_addr, int UT, int k1, int k2, int kc, int kr, int hmask,
-                                             sw_i32x4p erc, int cinc, int (&polls)[2]) {
-    int status;
-    const int need0 = 1 + k1 - 32;    // + 16 per block: the left progress that makes a whole block's halo readable
-    const int kc32 = kc + 32, kr32 = kr + 32;
-    asm volatile(
-        "s_setprio 3\n\t"
-        "s_mov_b32 %[status], 0\n\t"
-        "s_mov_b32 s83, %[need0]\n\t"
-        "s_mov_b32 s94, 0\n\t"
-        "s_mov_b32 s95, 0\n\t"
-        "s_mov_b32 s88, 1\n\t"
-        "s_mov_b32 s90, 0\n\t"
-        "s_mov_b32 s75, 0\n\t"
-        "s_mov_b32 s76, %[e0]\n\t"
-        "s_mov_b32 s77, %[e1]\n\t"
-        "s_mov_b32 s78, %[e2]\n\t"
-        "s_mov_b32 s79, %[e3]\n\t"
-        "s_and_b32 s91, %[hoff4], %[hmask]\n\t"
-        "s_mov_b64 s[92:93], %[cbase]\n\t"
-        "v_mov_b32 v96, %[voff]\n\t"
-        "v_mov_b32 v97, %[expoff]\n\t"
-        "v_mov_b32 v88, %[cntaddr]\n\t"
-        "v_mov_b32 v89, %[consaddr]\n\t"
-        "v_mov_b32 v90, %[rightaddr]\n\t"
-        "v_mov_b32 v91, %[progaddr]\n\t"
-        "v_mov_b32 v115, %[g0]\n\t"               /* step 0: every lane holds its row-0 value */
-        "v_mov_b32 v118, %[tm1]\n\t"              /* t of step -1 */
-        "v_mov_b32 v121, %[z1]\n\t"               /* floor of step 1 */
-        "v_mov_b32 v86, 0\n\t"                    /* left progress as last sampled: nothing yet -> the first block takes the slow path */
-        "v_mov_b32 v87, 0\n\t"                    /* my progress (completed local steps) */
-        "v_mov_b32 v80, 0\n\t"
-        "v_mov_b32 v81, 0\n\t"
-        "v_mov_b32 v82, 0\n\t"
-        "v_mov_b32 v83, 0\n\t"
-        "v_mov_b32 v52, 0\n\t"
-        "v_mov_b32 v53, 0\n\t"
-        "v_mov_b32 v54, 0\n\t"
-        "v_mov_b32 v55, 0\n\t"
-        "v_mov_b32 v84, 0\n\t"
-        "s_nop 4\n\t"
-        "global_load_dwordx4 v[76:79], v96, s[92:93] offset:0\n\t"     /* the block before the first: its last byte is step 0 */
-        "global_load_dwordx4 v[64:67], v96, s[92:93] offset:16\n\t"
-        "global_load_dwordx4 v[68:71], v96, s[92:93] offset:32\n\t"
-        "global_load_dwordx4 v[72:75], v96, s[92:93] offset:48\n\t"
-        "s_add_u32 s92, s92, 64\n\t"
-        "s_addc_u32 s93, s93, 0\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_perm_b32 v63, %[phi], %[plo], v79\n"
-        "Lchunk_%=:\n\t"
-        PP_K_BP(PP_BPCHECK("A", "%[kc]", "%[kr]"))
-        "v_add_u32 v126, s90, %[wbase]\n\t"
-        "v_mov_b32 v98, %[hbase]\n\t"
-        "v_add_u32 v98, s91, v98\n\t"
-        "s_add_i32 s91, s91, 256\n\t"
-        "s_and_b32 s91, s91, %[hmask]\n\t"
-        "v_mov_b32 v99, %[hbase]\n\t"
-        "v_add_u32 v99, s91, v99\n\t"
-        PP_BLOCK(0, "v63", "v122", "v123", "v124", "v125", "v64", "v65", "v66", "v67", "v[76:79]", "0", "0", "16", "32", "48",
-                 "48", "v98 offset:64", "v98 offset:80", "v98 offset:96", "4", "4", "")
-        PP_BLOCK(16, "v125", "v60", "v61", "v62", "v63", "v68", "v69", "v70", "v71", "v[64:67]", "16", "64", "80", "96", "112",
-                 "112", "v98 offset:128", "v98 offset:144", "v98 offset:160", "4", "4", PP_BPFETCH)
-        PP_K_BP(PP_BPCHECK("B", "%[kc32]", "%[kr32]"))
-        PP_BLOCK(32, "v63", "v122", "v123", "v124", "v125", "v72", "v73", "v74", "v75", "v[68:71]", "32", "128", "144", "160", "176",
-                 "176", "v98 offset:192", "v98 offset:208", "v98 offset:224", "4", "4", "")
-        PP_BLOCK(48, "v125", "v60", "v61", "v62", "v63", "v76", "v77", "v78", "v79", "v[72:75]", "48", "192", "208", "224", "240",
-                 "240", "v99", "v99 offset:16", "v99 offset:32", "4", "4", PP_BPFETCH)
-        "s_add_i32 s90, s90, 256\n\t"
-        "s_and_b32 s90, s90, 1023\n\t"
-        "s_add_i32 s75, s75, 256\n\t"
-        "s_add_u32 s92, s92, %[cinc]\n\t"
-        "s_addc_u32 s93, s93, 0\n\t"
-        "s_add_i32 s88, s88, 64\n\t"
-        "s_cmp_gt_i32 s88, %[ut]\n\t"
-        "s_cbranch_scc0 Lchunk_%=\n\t"
-        "s_branch Lexit_%=\n"
-        PP_SLOW(0, "0", "16", "32") PP_SLOW(16, "64", "80", "96") PP_SLOW(32, "128", "144", "160") PP_SLOW(48, "192", "208", "224")
-        "Lbpfail_%=:\n\t"
-        "s_mov_b32 %[status], 2\n"
-        "Lexit_%=:\n\t"
-        "s_setprio 0\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        "s_mov_b32 %[nbp], s94\n\t"
-        "s_mov_b32 %[nhalo], s95\n\t"
-        : [status] "=&s"(status), [nbp] "=&s"(polls[0]), [nhalo] "=&s"(polls[1])
-        : [plo] "v"(plo), [phi] "v"(phi), [ngap] "v"(ngap_v), [wbase] "v"(wbase), [voff] "v"(voff), [z1] "v"(z1), [g0] "v"(g0), [tm1] "v"(tm1),
-          [expoff] "v"(expoff), [cbase] "s"(cbase), [hbase] "s"(hbase), [hoff4] "s"(hoff4), [cntaddr] "s"(cnt_addr), [consaddr] "s"(cons_addr),
-          [rightaddr] "s"(right_addr), [progaddr] "s"(prog_addr), [ut] "s"(UT), [need0] "s"(need0), [k2] "s"(k2), [kc] "s"(kc), [kr] "s"(kr),
-          [kc32] "s"(kc32), [kr32] "s"(kr32), [hmask] "s"(hmask), [e0] "s"(erc.x), [e1] "s"(erc.y), [e2] "s"(erc.z), [e3] "s"(erc.w), [cinc] "s"(cinc)
-        : "vcc", "scc", "memory", "s75", "s76", "s77", "s78", "s79", "s83", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94",
-          "s95", "v52", "v53", "v54", "v55", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77",
-          "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v96", "v97", "v98", "v99", "v100",
-          "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116",
-          "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126");
-    return status;
-}
+#define PP_BLOCK(V, ...) PP_BLOCK_(V, __VA_ARGS__)
+#define PP_SLOW_(V, ...) PP_SLOW_##V(__VA_ARGS__)
+#define PP_SLOW(V, ...) PP_SLOW_(V, __VA_ARGS__)
+#define PPV 0
+#define PP_FN producer_perm_progress
+#include "sw_perm_producer.inc"
+#undef PPV
+#undef PP_FN
+#define PPV 1
+#define PP_FN producer_perm_valid
+#include "sw_perm_producer.inc"
+#undef PPV
+#undef PP_FN
 
 
 // =================================================================================================
@@ -1124,8 +1099,10 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
         if (threadIdx.x < NS) lds.prod_u[threadIdx.x] = 0;
         if (threadIdx.x < NS * 8) lds.cons_blk[threadIdx.x / 8][threadIdx.x % 8] = ((int)(threadIdx.x % 8) < NC) ? -1 : 0x7fffffff;
         if (threadIdx.x == 0) { lds.halo_ready = 1; lds.exp_done = 0; lds.never = 0x7fffffff; }
-        if (p.debug_flags & 2048)   // poison the halo ring: any slot consumed before an importer wrote it shows up in the output
-            for (int i = threadIdx.x; i < SY_RH; i += blockDim.x) lds.halo[i] = p.gbias + 0x700000u + (u32)i;
+        // the halo ring starts empty: the perm producer takes a 0 for "not imported yet" (every G carries the launch bias)
+        for (int i = threadIdx.x; i < SY_RH; i += blockDim.x) lds.halo[i] = 0u;
+        if ((p.debug_flags & 2048) && p.gbias == 0)   // round-1 producers: poison the halo ring, so that any slot consumed before an
+            for (int i = threadIdx.x; i < SY_RH; i += blockDim.x) lds.halo[i] = 0x700000u + (u32)i;   // importer wrote it shows up in the output
         const int s0 = grp * NS;
         const int nact = min(NS, p.nstrips - s0);  // active strips of this group
         const bool has_top = (p.top != nullptr) || (p.top_gran != nullptr);
@@ -1246,7 +1223,13 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                     const uint64_t eb = (uint64_t)(uintptr_t)(p.edge4 + (int64_t)s * p.e4stride);
                     const sw_i32x4p erc = {(int)(u32)eb, (int)(u32)(eb >> 32), 0x7FFFFF00, 0x00020000};
                     int polls[2];
-                    const int st = producer_perm(prof_lo, prof_hi, ngap_v, wbase, voff, z1, G0v, G0v + (u32)SW_PERM_PAD, expoff, cb, hbase, hoff * 4, cnt_addr,
+                    // halo from the importer's ring: validated on use (unfilled slots read 0); from the left producer's ring in
+                    // this workgroup: by its progress counter
+                    const int st = (lefthalo && !(p.debug_flags & 8192))   // (debug bit 13: the progress form everywhere, for A/B runs)
+                        ? producer_perm_valid(prof_lo, prof_hi, ngap_v, wbase, voff, z1, G0v, G0v + (u32)SW_PERM_PAD, expoff, cb, hbase, hoff * 4, cnt_addr,
+                                              (u32)(size_t)&lds.cons_blk[ls][0], (u32)(size_t)(has_right ? right_cnt : &lds.never),
+                                              (u32)(size_t)&lds.prod_u[ls], UT, k1, k2, kc, kr, hmask * 4 + 3, erc, (p.debug_flags & 32) ? 0 : 64, polls)
+                        : producer_perm_progress(prof_lo, prof_hi, ngap_v, wbase, voff, z1, G0v, G0v + (u32)SW_PERM_PAD, expoff, cb, hbase, hoff * 4, cnt_addr,
                                                  (u32)(size_t)&lds.cons_blk[ls][0], (u32)(size_t)(has_right ? right_cnt : &lds.never),
                                                  (u32)(size_t)&lds.prod_u[ls], UT, k1, k2, kc, kr, hmask * 4 + 3, erc, (p.debug_flags & 32) ? 0 : 64, polls);
                     if (p.dbg && lane == 0) {
@@ -1597,7 +1580,9 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                         const int front = lds_load(&lds.halo_ready);
                         if (front > 1) impu = max(impu, front);
                         if (impu > ulast) break;
-                        int lim = min(ulast + 1, lds_load(&lds.prod_u[0]) + SY_RH - 2 * SY_U);   // steps < lim may be written
+                        // steps < lim may be written.  Every valid write also zeroes the slot half a ring further on (the producer
+                        // tells by the zero that a slot has not been filled yet), so only half of the ring holds unconsumed steps.
+                        int lim = min(ulast + 1, lds_load(&lds.prod_u[0]) + SY_RH / 2 - 2 * SY_U);
                         int base = impu;
                         auto windows = [&](auto NB) {
                             constexpr int nbat = decltype(NB)::value;
@@ -1629,6 +1614,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
                                 if (base == impu + b4 * 64 && npre > 0) {
                                     if (lane < npre && (front2 <= 1 || u >= front2)) {
                                         __hip_atomic_store(&lds.halo[(u - 1) & (SY_RH - 1)], vals[b4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        __hip_atomic_store(&lds.halo[(u - 1 + SY_RH / 2) & (SY_RH - 1)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                         if (p.dbg && (p.debug_flags & 512) && u < 256) p.dbg[1024 + (int64_t)s0 * 1024 + u] = ((u64)(u32)wave << 32) | vals[b4];
                                     }
                                     base += npre;

@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(64) prod_k(const unsigned char* codes, u32* ed
     const uint64_t eb = (uint64_t)(uintptr_t)edge;
     const sw_i32x4p erc = {(int)(u32)eb, (int)(u32)(eb >> 32), 0x7FFFFF00, 0x00020000};
     u64 r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
-    const int st = producer_perm(plo, phi, 2u, (u32)(size_t)&ring[0] + lane * SY_LSTR, 63u - lane, 0x55010000u, 0x55010000u + 2 * lane, 0x55010000u + 2 * lane - 100,
+    const int st = producer_perm_progress(plo, phi, 2u, (u32)(size_t)&ring[0] + lane * SY_LSTR, 63u - lane, 0x55010000u, 0x55010000u + 2 * lane, 0x55010000u + 2 * lane - 100,
                                  lane == 63 ? 0u : SY_OOB, codes + 64, (u32)(size_t)&halo[0], 0, (u32)(size_t)&left_cnt, (u32)(size_t)&cons[0],
                                  (u32)(size_t)&right_cnt, (u32)(size_t)&prog, UT, 32, 0x7ffffff0, 30 - SY_R, -SY_R - 32, SY_RH * 4 - 1, erc, 64, polls);
     u64 t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
