@@ -209,7 +209,7 @@ int sw_row_checksums_device(sw_ctx* ctx, const void* d_X, int elem_bytes, int64_
 
 /* ---- output buffers placed for speed -------------------------------------------------------
  * Where H and P lie in physical memory moves a 16384^2 fill by up to 25 % (their two store streams can meet in the
- * same DRAM banks).  sw_alloc_outputs allocates up to `trials` candidate pairs (0 = 6; 1 = a plain allocation, no trial
+ * same DRAM banks).  sw_alloc_outputs allocates up to `trials` candidate pairs (0 = 10; 1 = a plain allocation, no trial
  * fills), runs three fills of the caller's problem into each on the default stream and keeps the fastest; trial_ms
  * (optional, `trials` floats) receives the time of every candidate tried, 0 for those not needed.  The contents of the
  * returned buffers are the last trial fill.  Release with sw_free_outputs (d_P may sit inside a larger allocation). */
@@ -229,10 +229,11 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *   "engine"            0 systolic (default), 1 strip_scan
  *   "strips_per_group"  systolic: strips (producer waves) per workgroup, 1 or 2 (0: 1 for a single pair with up to
  *                       4.5 strips per CU or a batch that fits the CUs at once, else 2)
- *   "consumers"         systolic: consumer waves per strip: 2, 3, 4; also 6, 7 with one strip per group (0: 6 / 4; 8 is taken as 7)
+ *   "consumers"         systolic: consumer waves per strip: 2, 3, 4; also 6, 7 with one strip per group (0: with one strip per
+ *                       group 4 up to ~3.5e8 cells and 6 above, with two strips 4; 8 is taken as 7)
  *   "store_policy"      systolic H/P stores: 0 by problem size, 1 write-back, 2 streaming (nt)
- *   "importers"         systolic, one strip per workgroup: waves polling the left neighbour's edge column (default 2;
- *                       at most what 12 waves per workgroup leave)
+ *   "importers"         systolic, one strip per workgroup: waves polling the left neighbour's edge column, besides the one that
+ *                       always does (0: 4 up to ~3.5e8 cells, 2 above; at most what 12 waves per workgroup leave)
  *   "xcd_order"         systolic: 1 = neighbouring strip groups run on the same XCD
  *   "pace_ps"           systolic: strip 0 releases one row per this many picoseconds (0 = unpaced)
  *   "band_wait_ms"      sw_fill_band_device: how long a strip waits for its halo granules before the launch aborts

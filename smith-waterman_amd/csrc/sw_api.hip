@@ -52,7 +52,7 @@ struct sw_ctx {
     int64_t opt_debug = 0;
     int64_t opt_store_policy = 0;       // systolic H/P stores: 0 auto (by size), 1 write-back, 2 streaming (nt)
     int64_t opt_xcd_order = 0;          // systolic: 1 = neighbouring strip groups on one XCD
-    int64_t opt_importers = 2;          // systolic, one strip per workgroup: importer waves (as far as 12 waves allow)
+    int64_t opt_importers = 0;          // systolic, one strip per workgroup: importer waves (as far as 12 waves allow); 0 = by problem size
     int64_t opt_pace_ps = 0;            // systolic: pacing of strip 0 (ps per row; 0 = off)
     int64_t opt_dbg_ptr = 0;
     int64_t opt_band_wait_ms = 20000;   // band-resident launch: patience of the top-halo poll
@@ -112,7 +112,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "pace_ps")) { c->opt_pace_ps = v; return SW_OK; }
     if (!strcmp(name, "store_policy")) { if (v < 0 || v > 2) return SW_EINVAL; c->opt_store_policy = v; return SW_OK; }
     if (!strcmp(name, "xcd_order")) { c->opt_xcd_order = v ? 1 : 0; return SW_OK; }
-    if (!strcmp(name, "importers")) { if (v < 0 || v > 8) return SW_EINVAL; c->opt_importers = v ? v : 2; return SW_OK; }
+    if (!strcmp(name, "importers")) { if (v < 0 || v > 8) return SW_EINVAL; c->opt_importers = v; return SW_OK; }
     if (!strcmp(name, "debug_buf")) { c->opt_dbg_ptr = v; return SW_OK; }
     if (!strcmp(name, "band_wait_ms")) { c->opt_band_wait_ms = v > 0 ? v : 20000; return SW_OK; }
     if (!strcmp(name, "debug_epoch8")) { c->epoch8 = (unsigned)(v & 255); return SW_OK; }   // development aid: next launch tag = v + 1
@@ -262,7 +262,12 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         // for 20000 pairs, 203 vs 143 for 64).
         int NS = (int)c->opt_strips_per_group, NC = (int)c->opt_consumers;
         if (NS == 0) NS = (j.npairs == 1 ? (double)S <= 4.5 * c->num_cus : (double)S * (double)j.npairs <= (double)c->num_cus) ? 1 : 2;
-        if (NC == 0) NC = (NS == 1) ? 6 : 4;   // NS == 1: 6 consumers + exporter + 2 importers on the three SIMDs the producer leaves
+        // NS == 1: nine waves on the three SIMDs the producer leaves.  A chain-bound fill (one pair, up to ~3.5e8 cells: 16384^2)
+        // wants the hand-off found early -- 4 consumers + 5 importer waves: 240 vs 232 GCUPS at 16384^2, +7 % at 8192^2; bigger
+        // fills are bound by the stores and want 6 consumers + 3 importer waves (65536^2: 389 vs 340 GCUPS).
+        const bool chain_bound = NS == 1 && j.npairs == 1 && (double)cols * (double)rows <= 3.5e8;
+        if (NC == 0) NC = (NS == 1) ? (chain_bound ? 4 : 6) : 4;
+        const int importers = c->opt_importers > 0 ? (int)c->opt_importers : (chain_bound && NC <= 4 ? 4 : 2);
         if (NS == 1 && NC > 7) NC = 7;         // nine waves off the producer's SIMD: at most 7 consumers + exporter + importer
         // padded copies of b per problem: [front | b | tail]; front covers the fast producers' phi (< strips) + 63 lanes
         // (+ one 16-step block: the perm producer's first score window ends at step 0)
@@ -328,7 +333,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         if (NS == 1) {
             // wave 0 (the producer) owns SIMD 0: waves 4, 8, 12 idle; consumers, the exporter and the importers are the
             // K waves off SIMD 0 (wave id of ordinal k: k + 1 + k/3)
-            const int K = std::min<int>(9, NC + 1 + (int)std::max<int64_t>(1, c->opt_importers));   // 12 waves: 3 per SIMD
+            const int K = std::min<int>(9, NC + 1 + std::max(1, importers));   // 12 waves: 3 per SIMD
             threads = 64 * (K + (K - 1) / 3 + 1);
         } else {
             threads = 64 * (NS * (1 + NC) + 2);
@@ -604,7 +609,7 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
         return SW_EINVAL;
     }
     HIP_TRY(hipSetDevice(c->device));
-    if (trials <= 0) trials = 6;
+    if (trials <= 0) trials = 10;
     const size_t cells = (size_t)(cols + 1) * (size_t)(rows + 1);
     const size_t hbytes = cells * (size_t)h_elem_bytes, pbytes = cells * (size_t)p_elem_bytes;
     const size_t phase = 4u << 20;
@@ -624,8 +629,8 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
         // 1.12 ms when H and P lie on different sides of the 64 GiB mark and 1.38-1.47 ms when they share a side, whatever
         // their distance.  So from the second candidate on a spacer of 64 GiB (then 32, 96, 48, 80) is allocated between
         // H and P -- and released again when the search ends: no memory stays held.
-        static const int kSpacerGiB[6] = {0, 64, 96, 32, 128, 48};
-        size_t sp = (i > 0 && hbytes < (8ull << 30)) ? (size_t)kSpacerGiB[i % 6] << 30 : 0;
+        static const int kSpacerGiB[10] = {0, 64, 96, 32, 128, 48, 160, 80, 16, 112};
+        size_t sp = (i > 0 && hbytes < (8ull << 30)) ? (size_t)kSpacerGiB[i % 10] << 30 : 0;
         if (sp) {
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < sp + pbytes + (8ull << 30)) sp = 0;   // not enough head room: plain candidate

@@ -17,7 +17,7 @@ TUNINGS = [
     {"strips_per_group": 2, "consumers": 2}, {"strips_per_group": 2, "consumers": 3}, {"strips_per_group": 2, "consumers": 4}, {"strips_per_group": 1, "consumers": 2},
     {"strips_per_group": 1, "consumers": 3}, {"strips_per_group": 1, "consumers": 4}, {"strips_per_group": 1, "consumers": 6},
     {"strips_per_group": 1, "consumers": 8}, {"store_policy": 1}, {"store_policy": 2}, {"xcd_order": 1},
-    {"xcd_order": 1, "max_blocks": 20}, {"pace_ps": 40000}, {"importers": 2}, {"importers": 2, "strips_per_group": 1, "consumers": 4}, {"store_policy": 2, "xcd_order": 1, "strips_per_group": 1, "consumers": 8},
+    {"xcd_order": 1, "max_blocks": 20}, {"pace_ps": 40000}, {"importers": 2}, {"importers": 1}, {"importers": 4, "consumers": 6}, {"importers": 6, "strips_per_group": 1, "consumers": 2}, {"importers": 2, "strips_per_group": 1, "consumers": 4}, {"store_policy": 2, "xcd_order": 1, "strips_per_group": 1, "consumers": 8},
 ]
 
 
