@@ -37,6 +37,7 @@ struct sw_multi_band {
     void *d_H = nullptr, *d_P = nullptr;
     uint64_t *d_top = nullptr, *d_bot = nullptr;
     bool host_gran = false;            // granule buffers in host-pinned memory (bands sharing one GPU: see sw_multi_create)
+    bool placed = false;               // d_H / d_P come from sw_alloc_outputs (a band with a GPU of its own)
     uint32_t* h_done = nullptr;        // host-pinned, one flag per strip
     sw_result* d_res = nullptr;
     hipStream_t stream = nullptr, copy = nullptr;
@@ -61,7 +62,9 @@ void sw_multi_free(sw_multi* m) {
         (void)hipSetDevice(b.device);
         if (b.stream) (void)hipStreamDestroy(b.stream);
         if (b.copy) (void)hipStreamDestroy(b.copy);
-        (void)hipFree(b.d_a); (void)hipFree(b.d_b); (void)hipFree(b.d_H); (void)hipFree(b.d_P);
+        (void)hipFree(b.d_a); (void)hipFree(b.d_b);
+        if (b.placed && b.ctx) (void)sw_free_outputs(b.ctx, b.d_H, b.d_P);
+        else { (void)hipFree(b.d_H); (void)hipFree(b.d_P); }
         if (b.host_gran) { if (b.d_top) (void)hipHostFree(b.d_top); if (b.d_bot) (void)hipHostFree(b.d_bot); }
         else { (void)hipFree(b.d_top); (void)hipFree(b.d_bot); }
         (void)hipFree(b.d_res);
@@ -114,16 +117,25 @@ int sw_multi_create(const int* devices, int ndev, const char* a, int64_t cols, c
             return true;
         };
         bool ok = dev_alloc((void**)&bd.d_a, (size_t)cols + 16) && dev_alloc((void**)&bd.d_b, (size_t)br + 16) &&
-                  (!want_h || dev_alloc(&bd.d_H, cells * 4)) && dev_alloc(&bd.d_P, cells * (size_t)p_elem_bytes) &&
-                  dev_alloc((void**)&bd.d_res, sizeof(sw_result)) && (g == 0 || gran_alloc(&bd.d_top)) && (g == nb - 1 || gran_alloc(&bd.d_bot));
+                  hipMemcpy(bd.d_a, a, (size_t)cols, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMemcpy(bd.d_b, b + bd.lo, (size_t)br, hipMemcpyHostToDevice) == hipSuccess;
+        // A band with a GPU of its own takes H and P from the placement-aware allocator (trial fills of the band's own problem:
+        // where the two matrices lie in HBM moves a fill by 15-30 %).  Bands sharing a GPU cannot: a trial
+        // fill wants the whole device.
+        if (ok && want_h && share0 == 1) {
+            const sw_scores trial = {3, -3, -2};
+            ok = sw_alloc_outputs(bd.ctx, bd.d_a, cols, bd.d_b, br, &trial, 4, p_elem_bytes, cells > (1ull << 32) ? 4 : 0, &bd.d_H, &bd.d_P, nullptr) == SW_OK;
+            bd.placed = ok;
+        } else {
+            ok = ok && (!want_h || dev_alloc(&bd.d_H, cells * 4)) && dev_alloc(&bd.d_P, cells * (size_t)p_elem_bytes);
+        }
+        ok = ok && dev_alloc((void**)&bd.d_res, sizeof(sw_result)) && (g == 0 || gran_alloc(&bd.d_top)) && (g == nb - 1 || gran_alloc(&bd.d_bot));
         if (!ok) { (void)hipGetLastError(); set_err("sw_multi_create: band %d does not fit device %d", g, bd.device); rc = SW_ENOMEM; break; }
         if (g < nb - 1 && hipHostMalloc((void**)&bd.h_done, (size_t)S * 4, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {
             set_err("sw_multi_create: pinned allocation failed"); rc = SW_ENOMEM; break;
         }
         if (bd.h_done) memset(bd.h_done, 0, (size_t)S * 4);
         if (hipStreamCreateWithFlags(&bd.stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&bd.copy, hipStreamNonBlocking) != hipSuccess ||
-            hipMemcpy(bd.d_a, a, (size_t)cols, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(bd.d_b, b + bd.lo, (size_t)br, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemset(bd.d_P, 0, (size_t)(cols + 1) * (size_t)p_elem_bytes) != hipSuccess ||   // row 0 of a band belongs to the band above: NONE stops a walk there
             (bd.d_top && !bd.host_gran && hipMemset(bd.d_top, 0, (size_t)(cols + 1) * 8) != hipSuccess) ||
             (bd.d_bot && !bd.host_gran && hipMemset(bd.d_bot, 0, (size_t)(cols + 1) * 8) != hipSuccess)) {

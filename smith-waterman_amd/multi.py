@@ -210,7 +210,7 @@ class BandResident(BandPipeline):
                 # which tries a few placements with fills of this band.  Its trial fills use the whole GPU, so not when
                 # several ranks may share one (gloo rehearsals).
                 self._out, self.placement_ms = engine.alloc_outputs(self.d_a, self.d_b, self.cols, br, p_dtype=p_dtype, scores=scores,
-                                                                    trials=4 if (br + 1) * (self.cols + 1) > (1 << 32) else 0)
+                                                                    trials=self._placement_trials(br, p_dtype))
                 self.H, self.P = self._out.H, self._out.P
                 self.H[0].zero_()
                 self.P[0].zero_()
@@ -235,6 +235,12 @@ class BandResident(BandPipeline):
             t.cuda.synchronize()
 
     # columns of chunk k (granule indices): strips [s0, s1) own columns 63*s0+1 .. 63*s1; column 0 rides with the first chunk
+    def _placement_trials(self, br, p_dtype):
+        # every candidate holds one more copy of P until the search ends: fewer candidates for bands that fill the HBM
+        cells = (br + 1) * (self.cols + 1)
+        total = cells * (4 + (1 if p_dtype is not None and p_dtype.itemsize == 1 else 4))
+        return 0 if cells <= (1 << 32) else (4 if total <= (100 << 30) else 2)
+
     # Cut at even granule indices: every forwarded piece is then 16-byte aligned, so no transport has a reason to move a
     # granule in pieces smaller than its 8 bytes (a granule is valid only as a whole).  A granule that is cut off rides
     # with the next chunk; its strip is finished by then.
