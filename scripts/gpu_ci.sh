@@ -30,6 +30,7 @@ step bench_p8 300 python bench.py --steps 10 --warmup 2 --no-cpu --p8
 step bench_bands_1gpu_16k 300 python bench.py --mode bands --cols 16384 --rows 16384 --steps 10 --warmup 2
 step bench_bands_1gpu_128k_p8 600 python bench.py --mode bands --cols 131072 --rows 131072 --steps 2 --warmup 1 --p8
 step bench_band_n8_shape_p8 600 python bench.py --mode bands --cols 262144 --rows 32768 --steps 3 --warmup 1 --p8
+step bench_config4_one_gpu_p_only 600 python bench.py --mode bands --cols 262144 --rows 262144 --p8 --no-h --steps 2 --warmup 1
 step bench_rehearsal_2ranks_gloo_1gpu 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --cols 32768 --rows 32768
 step cli_16384 300 ./smith-waterman_amd/smithW 16384 16384
 step cli_2bands_1gpu_16384 300 ./smith-waterman_amd/smithW --devices 0,0 16384 16384

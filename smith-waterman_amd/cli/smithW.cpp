@@ -2,7 +2,7 @@
 //   smithW                  built-in 8x9 example (serial_smithW.c:105-125) + its known-answer checks
 //   smithW <cols> <rows>    random DNA pair from the reference generator (seed 1 == serial_smithW.c)
 //   smithW --fasta A.fa B.fa   real sequences: a = first record of A.fa (columns), b = first record of B.fa (rows)
-// Extra flags (after the positional ones): --seed N  --dump  --h64  --no-backtrack  --scores M X G  --record-a I  --record-b J
+// Extra flags: --seed N  --dump | --dump-labels (the header-row printers of omp_smithW.c)  --h64  --no-backtrack  --scores M X G  --record-a I  --record-b J
 //   --gpus N | --devices 0,1,..   ONE matrix over several GPUs (row bands, sw_multi_*; an id may repeat)  --p8  int8 P
 // The DP fill runs on the GPU through the C-ABI (include/swhip.h); stdout keeps the two
 // "Elapsed time ..." lines the reference's run scripts grep for (readme.liao:12).
@@ -47,9 +47,35 @@ static void print_pred(const std::vector<int32_t>& P, long long n, long long m) 
     }
 }
 
+// the labelled variants (sequence a as a header row, the letters of b in front of the rows), omp_smithW.c:426-483
+static void print_matrix_labelled(const std::vector<int32_t>& H, long long n, long long m, const char* a, const char* b) {
+    printf("-\t-\t");
+    for (long long j = 0; j + 1 < m; j++) printf("%c\t", a[j]);
+    printf("\n-\t");
+    for (long long i = 0; i < n; i++) {
+        if (i > 0) printf("%c\t", b[i - 1]);
+        for (long long j = 0; j < m; j++) printf("%d\t", H[m * i + j]);
+        printf("\n");
+    }
+}
+static void print_pred_labelled(const std::vector<int32_t>& P, long long n, long long m, const char* a, const char* b) {
+    printf("    ");
+    for (long long j = 0; j + 1 < m; j++) printf("%c ", a[j]);
+    printf("\n  ");
+    for (long long i = 0; i < n; i++) {
+        if (i > 0) printf("%c ", b[i - 1]);
+        for (long long j = 0; j < m; j++) {
+            const int v = P[m * i + j], av = v < 0 ? -v : v;
+            const char* sym = av == SW_UP ? "↑ " : av == SW_LEFT ? "← " : av == SW_DIAGONAL ? "↖ " : "- ";
+            if (v < 0) printf(BOLDRED "%s" RESET, sym); else printf("%s", sym);
+        }
+        printf("\n");
+    }
+}
+
 int main(int argc, char** argv) {
     long long cols = 8, rows = 9;
-    bool builtin = true, dump = false, h64 = false, backtrack = true, p8 = false;
+    bool builtin = true, dump = false, labels = false, h64 = false, backtrack = true, p8 = false;
     std::vector<int> devices;
     unsigned seed = 1;
     const char *fasta_a = nullptr, *fasta_b = nullptr;
@@ -64,6 +90,7 @@ int main(int argc, char** argv) {
             ++npos;
         }
         else if (f == "--dump") dump = true;
+        else if (f == "--dump-labels") dump = labels = true;
         else if (f == "--h64") h64 = true;
         else if (f == "--no-backtrack") backtrack = false;
         else if (f == "--p8") p8 = true;
@@ -74,7 +101,7 @@ int main(int argc, char** argv) {
         else if (f == "--record-b" && ai + 1 < argc) rec_b = strtoll(argv[++ai], nullptr, 10);
         else if (f == "--seed" && ai + 1 < argc) seed = (unsigned)strtoul(argv[++ai], nullptr, 10);
         else if (f == "--scores" && ai + 3 < argc) { sc.match = atoi(argv[++ai]); sc.mismatch = atoi(argv[++ai]); sc.gap = atoi(argv[++ai]); }
-        else { fprintf(stderr, "usage: smithW [<cols> <rows> | --fasta A.fa B.fa [--record-a I] [--record-b J]] [--seed N] [--dump] [--h64] [--no-backtrack] [--scores M X G] [--gpus N | --devices 0,1,..] [--p8]\n"); return 2; }
+        else { fprintf(stderr, "usage: smithW [<cols> <rows> | --fasta A.fa B.fa [--record-a I] [--record-b J]] [--seed N] [--dump | --dump-labels] [--h64] [--no-backtrack] [--scores M X G] [--gpus N | --devices 0,1,..] [--p8]\n"); return 2; }
     }
     if (npos == 1) { fprintf(stderr, "smithW: <cols> needs <rows>\n"); return 2; }
     if (fasta_a) {
@@ -154,14 +181,14 @@ int main(int argc, char** argv) {
             for (size_t k = 0; k < cells; ++k) H[k] = (int32_t)H8[k];
         } else CHECK(sw_memcpy_d2h(ctx, H.data(), d_H, cells * 4));
         CHECK(sw_memcpy_d2h(ctx, P.data(), d_P, cells * 4));
-        if (dump) { printf("\nSimilarity Matrix:\n"); print_matrix(H, n, m); }
+        if (dump) { printf("\nSimilarity Matrix:\n"); if (labels) print_matrix_labelled(H, n, m, a.data(), b.data()); else print_matrix(H, n, m); }
         if (builtin) {
             // the reference's built-in checks: serial_smithW.c:162-166, omp_smithW-v1-refinedOrig.cpp:229-238
             const bool ok = H[m * n - 1] == 7 && res.max_pos == 69 && res.max_score == 13;
             printf("Verifying correctness using builtin data =%d\n", ok);
             if (!ok) rc = 1;
         }
-        if (dump) { printf("\nPredecessor Matrix:\n"); print_pred(P, n, m); }
+        if (dump) { printf("\nPredecessor Matrix:\n"); if (labels) print_pred_labelled(P, n, m, a.data(), b.data()); else print_pred(P, n, m); }
     }
     sw_device_free(ctx, d_a); sw_device_free(ctx, d_b); sw_free_outputs(ctx, d_H, d_P); sw_device_free(ctx, d_res);
     sw_destroy(ctx);

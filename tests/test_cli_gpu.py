@@ -87,3 +87,34 @@ def test_multi_gpu_flag_two_bands_on_one_gpu(oracle):
     H, P, mp = oracle.fill(a, b)
     path = oracle.backtrack(P, mp)
     assert f"maxPos = {mp}, H[maxPos] = {int(H.flat[mp])}, path length = {len(path)}" in r.stdout and "(2 row bands)" in r.stdout
+
+
+REF_OMP_DEBUG = os.path.join(ROOT, "oracle", "_ref", "omp_smithW_debug")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_OMP_DEBUG), reason="oracle/_ref/omp_smithW_debug is built in the build container only")
+def test_labelled_dump_is_byte_identical_to_the_reference_openmp_program(tmp_path):
+    """--dump-labels: the header-row printers of omp_smithW.c:426-483.  That program seeds rand() with time(), so its
+    sequences are read back from its own dump (header row = a, row labels = b) and given to the CLI as FASTA files; the two
+    matrix blocks, escape sequences of the red traceback path included, must then be identical byte for byte."""
+    ref = subprocess.run([REF_OMP_DEBUG, "37", "29"], capture_output=True, text=True, timeout=120, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert ref.returncode == 0, ref.stderr
+    block = ref.stdout.split("\nSimilarity Matrix:\n")[1]
+    lines = block.split("\n")
+    a = "".join(lines[0].split("\t")[2:]).strip()
+    b = "".join(ln.split("\t")[0] for ln in lines[2:2 + 29])
+    assert len(a) == 37 and len(b) == 29 and set(a + b) <= set("ACGT")
+    fa, fb = tmp_path / "a.fa", tmp_path / "b.fa"
+    fa.write_text(">a\n" + a + "\n")
+    fb.write_text(">b\n" + b + "\n")
+    r = run("--fasta", str(fa), str(fb), "--dump-labels")
+    assert r.returncode == 0, r.stderr
+    mine = r.stdout.split("\nSimilarity Matrix:\n")[1]
+    # omp_smithW.c keeps the first maximum in anti-diagonal order, serial_smithW.c (our rule) the lowest linear index: with a tied
+    # maximum the two programs may trace different paths, so the red path is only compared when the maximum is unique
+    cells = [int(x) for ln in lines[1:2 + 29] for x in ln.split("\t") if re.fullmatch(r"-?\d+", x)]
+    if cells.count(max(cells)) == 1:
+        assert mine.rstrip("\n") == block.rstrip("\n")
+    else:
+        strip = lambda t: re.sub(r"\x1b\[[0-9;]*m", "", t).rstrip("\n")
+        assert strip(mine) == strip(block)
