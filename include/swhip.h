@@ -198,6 +198,11 @@ int sw_traceback_device_ex(sw_ctx* ctx, void* d_P, int p_elem_bytes, int64_t col
 int sw_traceback_host_ex(void* P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos,
                          int64_t* path, int64_t path_cap, int64_t* path_len);
 
+/* Compact predecessor matrix back to the reference's layout (a compact P "must still round-trip to the
+ * int32 H/P layout"): d_P32[k] = (int32_t)d_P8[k] for k < count -- codes 0..3, and -1..-3 along a traced path.  The two
+ * buffers must not overlap. */
+int sw_p8_to_p32_device(sw_ctx* ctx, const void* d_P8, int32_t* d_P32, int64_t count, void* stream);
+
 /* ---- verification helpers (not on the timed path) ------------------------------------------
  * Position-weighted row checksums of a device matrix with (rows1 x m) elements:
  *   cs[i] = sum_j (uint64)(uint32)X[i][j] * ((j+1) * 0x9E3779B97F4A7C15)  (mod 2^64)

@@ -74,6 +74,7 @@ ABI = {
     "sw_traceback_device_ex": (_i32, [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
     "sw_fill_device_ex": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "sw_row_checksums_device": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
+    "sw_p8_to_p32_device": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "sw_alloc_outputs": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _i32, _i32, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                 ctypes.POINTER(ctypes.c_float)]),
     "sw_free_outputs": (_i32, [_vp, _vp, _vp]),
@@ -454,6 +455,13 @@ class Engine:
                                              cs.data_ptr(), self._stream()))
         self.synchronize()
         return cs.cpu().numpy().view(np.uint64)
+
+    def widen_p(self, P8):
+        """int8 predecessor matrix -> the reference's int32 layout (sw_p8_to_p32_device)."""
+        t = self.torch
+        out = t.empty(P8.shape, dtype=t.int32, device=P8.device)
+        _check(lib().sw_p8_to_p32_device(self._h, P8.data_ptr(), out.data_ptr(), P8.numel(), self._stream()))
+        return out
 
     def synchronize(self):
         _check(lib().sw_synchronize(self._h, self._stream()))

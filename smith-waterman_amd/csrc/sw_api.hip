@@ -721,6 +721,16 @@ int sw_synchronize(sw_ctx* c, void* stream_) {
     return SW_OK;
 }
 
+int sw_p8_to_p32_device(sw_ctx* c, const void* d_P8, int32_t* d_P32, int64_t count, void* stream_) {
+    if (!c || count < 0 || (count > 0 && (!d_P8 || !d_P32))) { set_err("sw_p8_to_p32_device: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (count == 0) return SW_OK;
+    const unsigned nb = (unsigned)std::min<int64_t>((count + 256 * 16 - 1) / (256 * 16), 8192);
+    hipLaunchKernelGGL(swk::sw_widen_p8, dim3(nb), dim3(256), 0, (hipStream_t)stream_, (const signed char*)d_P8, d_P32, (size_t)count);
+    HIP_TRY(hipGetLastError());
+    return SW_OK;
+}
+
 int sw_row_checksums_device(sw_ctx* c, const void* d_X, int elem_bytes, int64_t rows1, int64_t m, uint64_t* d_cs,
                             void* stream_) {
     if (!c || !d_X || !d_cs || rows1 <= 0 || m <= 0 || (elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 1) || rows1 > 0x7fffffff) {

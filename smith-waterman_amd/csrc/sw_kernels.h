@@ -69,5 +69,6 @@ __global__ void sw_traceback(PT* P, int64_t M, int64_t maxPos, int64_t* path, in
 template <typename PT>
 __global__ void sw_traceback_batch(PT* P, int64_t M, int64_t pstride, int64_t npairs, int64_t* paths, int64_t cap, sw_result* res);
 template <typename T> __global__ void sw_row_checksums(const T* X, int64_t m, unsigned long long* cs);
+__global__ void sw_widen_p8(const signed char* P8, int32_t* P32, size_t n);
 
 }  // namespace swk

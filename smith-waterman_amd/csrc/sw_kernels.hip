@@ -310,6 +310,21 @@ __global__ void sw_traceback_batch(PT* __restrict__ P, int64_t M, int64_t pstrid
     }
     res[k].path_len = len;
 }
+// compact predecessor matrix -> the reference's int32 layout (same codes, sign-extended): 16 codes per thread and pass
+__global__ void sw_widen_p8(const signed char* __restrict__ P8, int32_t* __restrict__ P32, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 16;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += stride) {
+        if (i + 16 <= n && (((uintptr_t)(P8 + i)) & 15) == 0 && (((uintptr_t)(P32 + i)) & 15) == 0) {
+            const int4 v = *(const int4*)(P8 + i);
+            const int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(int4*)(P32 + i + 4 * q) = make_int4((int)(signed char)(w[q]), (int)(signed char)(w[q] >> 8), (int)(signed char)(w[q] >> 16), (int)(signed char)(w[q] >> 24));
+        } else {
+            for (size_t k = i; k < n && k < i + 16; ++k) P32[k] = (int32_t)P8[k];
+        }
+    }
+}
 template __global__ void sw_traceback_batch<int32_t>(int32_t*, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*);
 template __global__ void sw_traceback_batch<signed char>(signed char*, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*);
 

@@ -62,6 +62,13 @@ def test_compact_p_int8(engine, oracle, swamd, engine_kind, cols, rows, h64):
     assert np.array_equal(path, opath) and np.array_equal(out.P.cpu().numpy().astype(np.int32), P1)
     hpath = swamd.traceback_host(P8, mp)
     assert np.array_equal(hpath, opath) and np.array_equal(P8.astype(np.int32), P1)
+    # round trip to the reference's int32 layout on the device (sw_p8_to_p32_device), negated path included
+    wide = engine.widen_p(out.P)
+    engine.synchronize()
+    assert wide.dtype == torch.int32 and np.array_equal(wide.cpu().numpy(), P1)
+    odd = engine.widen_p(out.P.view(-1)[3:-2])        # unaligned start and a ragged tail
+    engine.synchronize()
+    assert np.array_equal(odd.cpu().numpy(), P1.reshape(-1)[3:-2])
 
 
 def test_config3_65536_int64_streaming_checksums(engine, oracle, swamd, engine_kind):
