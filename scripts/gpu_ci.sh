@@ -36,6 +36,8 @@ step cli_16384 300 ./smith-waterman_amd/smithW 16384 16384
 step cli_2bands_1gpu_16384 300 ./smith-waterman_amd/smithW --devices 0,0 16384 16384
 step bench_batch_100k_scoreonly 600 python bench.py --mode batch --pairs 100000 --steps 1 --warmup 1
 step bench_batch_100k_p8_traceback 900 python bench.py --mode batch --pairs 100000 --steps 1 --warmup 0 --store --p8 --no-h --traceback
+step ubench_two_column_producer 100 ./tools/ubench_perm2
+step ubench_lds_write_order 100 ./tools/ubench_ldsorder
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof
 step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 20 --warmup 3 --no-cpu

@@ -243,49 +243,17 @@ class Engine:
             d[: len(s)] = t.from_numpy(s.copy())
         return d, len(s)
 
-    def alloc(self, cols: int, rows: int, h_dtype=None, p_dtype=None, spacer_bytes: int = 0, hold=None, want_h: bool = True,
-              want_p: bool = True):
-        """Output buffers: H int32|int64, P int32 (the reference layout) or int8 (compact P, same codes).
-        spacer_bytes: a block of that size is allocated between H and P and released again, so that the two
-        matrices land in different regions of the device memory (used by alloc_tuned)."""
+    def alloc(self, cols: int, rows: int, h_dtype=None, p_dtype=None, want_h: bool = True, want_p: bool = True):
+        """Plain output buffers (torch allocations): H int32|int64, P int32 (the reference layout) or int8 (compact P, same
+        codes); either may be left out (matrix-less fills).  For the placement that makes a big fill fast see alloc_outputs."""
         t = self.torch
         h_dtype = h_dtype or t.int32
         p_dtype = p_dtype or t.int32
         assert p_dtype in (t.int32, t.int8)
         dev = f"cuda:{self.device}"
-        if not (want_h and want_p):   # matrix-less fills (P-only, H-only, score-only): sw_fill_device_ex with NULL pointers
-            H = t.empty((rows + 1, cols + 1), dtype=h_dtype, device=dev) if want_h else None
-            P = t.empty((rows + 1, cols + 1), dtype=p_dtype, device=dev) if want_p else None
-            return Fill(H, P, t.zeros(3, dtype=t.int64, device=dev), cols, rows)
-        H = t.empty((rows + 1, cols + 1), dtype=h_dtype, device=dev)
-        n = (rows + 1) * (cols + 1)
-        spacer = None
-        if spacer_bytes > 0:
-            try:
-                spacer = t.empty(spacer_bytes, dtype=t.uint8, device=dev)
-            except RuntimeError:
-                spacer = None
-        if p_dtype == t.int8:
-            P = t.empty((rows + 1, cols + 1), dtype=t.int8, device=dev)
-        elif h_dtype == t.int32 and n * 4 >= (64 << 20):
-            # H[r][c] and P[r][c] are stored by the same wave within a fraction of a microsecond.  When the two
-            # addresses agree in their low 22 bits they land in the same DRAM bank (measured on MI355X: fill time
-            # periodic in (P - H) mod 4 MiB, worst at 0, best at 2 MiB, 5-9 % apart), so P is placed 2 MiB out of phase.
-            Pb = t.empty(n * 4 + (4 << 20), dtype=t.uint8, device=dev)
-            want = (H.data_ptr() + (2 << 20)) % (4 << 20)
-            off = (want - Pb.data_ptr()) % (4 << 20)
-            P = Pb[off:off + n * 4].view(t.int32).view(rows + 1, cols + 1)
-        else:
-            P = t.empty((rows + 1, cols + 1), dtype=t.int32, device=dev)
-        res = t.zeros(3, dtype=t.int64, device=dev)
-        out = Fill(H, P, res, cols, rows)
-        if spacer is not None:
-            if hold is not None:
-                hold.append(spacer)     # the caller keeps it (so that later allocations explore other regions) and frees it
-            else:
-                del spacer
-                t.cuda.empty_cache()
-        return out
+        H = t.empty((rows + 1, cols + 1), dtype=h_dtype, device=dev) if want_h else None
+        P = t.empty((rows + 1, cols + 1), dtype=p_dtype, device=dev) if want_p else None
+        return Fill(H, P, t.zeros(3, dtype=t.int64, device=dev), cols, rows)
 
     def alloc_outputs(self, d_a, d_b, cols: int, rows: int, h_dtype=None, p_dtype=None, trials: int = 0, scores=DEFAULT_SCORES):
         """Output buffers through the C-ABI allocator sw_alloc_outputs (what a C caller gets): candidate placements
@@ -307,41 +275,6 @@ class Engine:
         out = Fill(H, P, t.zeros(3, dtype=t.int64, device=f"cuda:{self.device}"), cols, rows)
         out._owner = owner
         return out, [x for x in ms if x > 0]
-
-    def alloc_tuned(self, d_a, d_b, cols: int, rows: int, h_dtype=None, trials: int = 4, fills: int = 3, p_dtype=None):
-        """alloc() with placement tuning: the fill's speed depends on where the driver put H and P in
-        physical memory (measured on MI355X: two modes ~15 % apart per allocation, same virtual addresses
-        or not).  Allocate up to `trials` candidate pairs of buffers, time `fills` fills into each and keep
-        the fastest; the others are released.  Returns (Fill, [ms of every candidate])."""
-        t = self.torch
-        best, best_ms, seen, held = None, float("inf"), [], []
-        n_bytes = (rows + 1) * (cols + 1) * 4
-        for i in range(max(1, trials)):
-            try:
-                # candidates differ in how far apart H and P are allocated (measured: the fast mode is about six
-                # times more frequent among such pairs than among back-to-back allocations, scripts/ab_scan.py, ab_spacer.py)
-                sp = ((i % 6) * 5 + 3) << 30 if (i > 0 and n_bytes < (4 << 30)) else 0
-                cand = self.alloc(cols, rows, h_dtype, p_dtype, spacer_bytes=sp, hold=held)
-            except RuntimeError:      # out of HBM: stay with what we have
-                break
-            self.fill_into(cand, d_a, d_b)
-            t.cuda.synchronize(self.device)
-            e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(fills):
-                self.fill_into(cand, d_a, d_b)
-            e1.record()
-            t.cuda.synchronize(self.device)
-            ms = e0.elapsed_time(e1) / fills
-            seen.append(ms)
-            held.append(cand)       # keep every candidate alive so the next one lands somewhere else
-            if ms < best_ms:
-                best, best_ms = cand, ms
-            if len(seen) >= 3 and best_ms < 0.92 * sorted(seen)[len(seen) // 2]:
-                break               # clearly in the fast mode: stop looking
-        held.clear()
-        t.cuda.empty_cache()
-        return best, seen
 
     def fill_into(self, out: Fill, d_a, d_b, scores=DEFAULT_SCORES, top=None):
         """Asynchronous fill on torch's current stream into pre-allocated buffers."""

@@ -1,0 +1,282 @@
+// tools/ubench_perm2.hip -- the producer step of a strip with TWO matrix columns per lane (the next
+// round's kernel), verified against a host restatement and timed.  Lane l owns columns A = 2l-1 and B = 2l of its strip and
+// works on the same row for both; per anti-diagonal step (7 VALU for two cells, 8 in the one-column producer):
+//     Z   += ngap                                   floor of this lane's B cell = floor of the next lane's A cell
+//     P    = max3(tB, gB1, Z)                       candidate for the NEXT lane's A cell (diagonal, left, floor)
+//     Q    = max3(tA, gB1, Z)                       diagonal, up and floor of my B cell
+//     tB'  = gB1 + sext(SA.byte)                    SA: scores of the next lane's A column (v_perm_b32 profile look-up)
+//     gA'  = max(P[l-1], gA1)                       v_max_i32_dpp wave_shr:1  (lane 0 is the halo lane: never written)
+//     gB'  = max3(Q, gA', Hin)                      Hin: lane 0 = the halo value of this step (ds_read_b128, 12 steps ahead),
+//                                                   other lanes = a value below every G
+//     tA'  = gA' + sext(SB.byte)                    SB: scores of my B column against the row below
+// Per 4 steps: two ds_write_b128 (ring A, ring B), one buffer_store_dwordx4 (lane 63's B column = the strip's right edge),
+// one ds_read_b128 (halo group of the next block); per 16 steps: 8 v_perm_b32, 2 code loads.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+typedef unsigned long long u64;
+typedef unsigned int u32;
+__device__ __forceinline__ u64 now_rt() { u64 t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
+__device__ __forceinline__ u64 now() { u64 t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
+
+// gA[k] = v(64+k), gB[k] = v(80+k), Hin[k] = v(100+k); tA = v116/v117, tB = v118/v119 (alternating), P v120, Z v121, Q v122
+#define S2(GA, GB, GA1, GB1, TAP, TAN, TBP, TBN, HIN, SA, SB, BYTE)                                                        \
+    "v_add_u32 v121, v121, %[ngap]\n\t"                                                                                   \
+    "v_max3_i32 v120, " TBP ", " GB1 ", v121\n\t"                                                                         \
+    "v_max3_i32 v122, " TAP ", " GB1 ", v121\n\t"                                                                         \
+    "v_add_u32_sdwa " TBN ", " GB1 ", sext(" SA ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BYTE "\n\t" \
+    "v_max_i32_dpp " GA ", v120, " GA1 " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                       \
+    "v_max3_i32 " GB ", v122, " GA ", " HIN "\n\t"                                                                        \
+    "v_add_u32_sdwa " TAN ", " GA ", sext(" SB ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BYTE "\n\t"
+#define EVEN(GA, GB, GA1, GB1, HIN, SA, SB, BYTE) S2(GA, GB, GA1, GB1, "v117", "v116", "v119", "v118", HIN, SA, SB, BYTE)
+#define ODD(GA, GB, GA1, GB1, HIN, SA, SB, BYTE) S2(GA, GB, GA1, GB1, "v116", "v117", "v118", "v119", HIN, SA, SB, BYTE)
+#define GRP0(SA, SB) EVEN("v64", "v80", "v79", "v95", "v100", SA, SB, "BYTE_0") ODD("v65", "v81", "v64", "v80", "v101", SA, SB, "BYTE_1")   \
+                     EVEN("v66", "v82", "v65", "v81", "v102", SA, SB, "BYTE_2") ODD("v67", "v83", "v66", "v82", "v103", SA, SB, "BYTE_3")
+#define GRP1(SA, SB) EVEN("v68", "v84", "v67", "v83", "v104", SA, SB, "BYTE_0") ODD("v69", "v85", "v68", "v84", "v105", SA, SB, "BYTE_1")   \
+                     EVEN("v70", "v86", "v69", "v85", "v106", SA, SB, "BYTE_2") ODD("v71", "v87", "v70", "v86", "v107", SA, SB, "BYTE_3")
+#define GRP2(SA, SB) EVEN("v72", "v88", "v71", "v87", "v108", SA, SB, "BYTE_0") ODD("v73", "v89", "v72", "v88", "v109", SA, SB, "BYTE_1")   \
+                     EVEN("v74", "v90", "v73", "v89", "v110", SA, SB, "BYTE_2") ODD("v75", "v91", "v74", "v90", "v111", SA, SB, "BYTE_3")
+#define GRP3(SA, SB) EVEN("v76", "v92", "v75", "v91", "v112", SA, SB, "BYTE_0") ODD("v77", "v93", "v76", "v92", "v113", SA, SB, "BYTE_1")   \
+                     EVEN("v78", "v94", "v77", "v93", "v114", SA, SB, "BYTE_2") ODD("v79", "v95", "v78", "v94", "v115", SA, SB, "BYTE_3")
+#ifdef NO_EXPORT
+#define KX(X) ""
+#else
+#define KX(X) X
+#endif
+#ifdef NO_RING
+#define KR(X) ""
+#else
+#define KR(X) X
+#endif
+// after group g of a block: ring writes of its 4 steps, the edge store, and the halo group g of the NEXT block
+// (WO: ring / edge byte offset of the group, HO: halo byte offset of the next block's group)
+#define TAIL(GA0, GA3, GB0, GB3, H0, H3, WO, HO)                                                                           \
+    KR("ds_write_b128 v99, v[" GA0 ":" GA3 "] offset:" WO "\n\t"                                                           \
+       "ds_write_b128 v123, v[" GB0 ":" GB3 "] offset:" WO "\n\t")                                                         \
+    KX("buffer_store_dwordx4 v[" GB0 ":" GB3 "], v97, s[76:79], s75 offen offset:" WO " sc1\n\t")                          \
+    "ds_read_b128 v[" H0 ":" H3 "], v98 offset:" HO "\n\t"
+#ifdef NO_RING
+#define LW "3"   /* only the reads are in the queue */
+#else
+#define LW "9"   /* the group's halo read is followed by 3 ops of each of the 3 groups before the next use */
+#endif
+// one 16-step block: CA/CB = code dwords of this block (for the A' and B score streams), NA/NB = the buffers that receive
+// the codes of the block two ahead (byte offset PF / PF+1), WB = ring byte offset of the block, HB = halo offset of the next block
+#define BLOCK(CA0, CA1, CA2, CA3, CB0, CB1, CB2, CB3, NA, NB, PF, PF1, W0, W1, W2, W3, H0, H1, H2, H3)                    \
+    "s_waitcnt vmcnt(" VMW ")\n\t"                                                                                        \
+    "v_perm_b32 v40, %[pahi], %[palo], " CA0 "\n\t"                                                                       \
+    "v_perm_b32 v41, %[pahi], %[palo], " CA1 "\n\t"                                                                       \
+    "v_perm_b32 v42, %[pahi], %[palo], " CA2 "\n\t"                                                                       \
+    "v_perm_b32 v43, %[pahi], %[palo], " CA3 "\n\t"                                                                       \
+    "v_perm_b32 v44, %[pbhi], %[pblo], " CB0 "\n\t"                                                                       \
+    "v_perm_b32 v45, %[pbhi], %[pblo], " CB1 "\n\t"                                                                       \
+    "v_perm_b32 v46, %[pbhi], %[pblo], " CB2 "\n\t"                                                                       \
+    "v_perm_b32 v47, %[pbhi], %[pblo], " CB3 "\n\t"                                                                       \
+    "global_load_dwordx4 " NA ", v96, s[92:93] offset:" PF "\n\t"                                                         \
+    "global_load_dwordx4 " NB ", v96, s[92:93] offset:" PF1 "\n\t"                                                        \
+    "s_waitcnt lgkmcnt(" LW ")\n\t"                                                                                       \
+    GRP0("v40", "v44") TAIL("64", "67", "80", "83", "100", "103", W0, H0)                                                 \
+    "s_waitcnt lgkmcnt(" LW ")\n\t"                                                                                       \
+    GRP1("v41", "v45") TAIL("68", "71", "84", "87", "104", "107", W1, H1)                                                 \
+    "s_waitcnt lgkmcnt(" LW ")\n\t"                                                                                       \
+    GRP2("v42", "v46") TAIL("72", "75", "88", "91", "108", "111", W2, H2)                                                 \
+    "s_waitcnt lgkmcnt(" LW ")\n\t"                                                                                       \
+    GRP3("v43", "v47") TAIL("76", "79", "92", "95", "112", "115", W3, H3)
+#ifdef NO_EXPORT
+#define VMW "2"    /* the two code loads of the block before */
+#else
+#define VMW "10"   /* 4 stores of the block two back, 2 loads + 4 stores of the block before */
+#endif
+
+struct Args {
+    const unsigned char* codes;   // lane l, step u: A' stream codes[OFF + u - l], B stream codes[OFF + 1 + u - l]
+    const int* halo;              // halo[u-1]: lane 0's B value of step u
+    const int* init;              // per lane: gA1, gB1, tA, tB, Z
+    const u32* prof;              // per lane: palo, pahi, pblo, pbhi
+    int* edge;                    // lane 63's B column, step-indexed
+    int ngap, low, nchunks;
+    int* outA; int* outB;
+    u64* clk;
+};
+
+template <int VERIFY>
+__global__ void __launch_bounds__(64) perm2_k(Args a) {
+    __shared__ __attribute__((aligned(16))) int ringA[64 * 260 + 64];   // lane-major: lane l at l*1040 bytes, 256 steps + pad
+    __shared__ __attribute__((aligned(16))) int ringB[64 * 260 + 64];
+    __shared__ __attribute__((aligned(16))) int halo[1024 + 128];
+    __shared__ __attribute__((aligned(16))) int lowv[128];              // what the lanes other than 0 read as "halo": below every G
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 1024 + 128; i += 64) halo[i] = a.halo[i];
+    for (int i = lane; i < 128; i += 64) lowv[i] = a.low;
+    __syncthreads();
+    const u32 palo = a.prof[4 * lane], pahi = a.prof[4 * lane + 1], pblo = a.prof[4 * lane + 2], pbhi = a.prof[4 * lane + 3];
+    const u32 ngap = (u32)a.ngap;
+    const u32 wA = (u32)(size_t)&ringA[0] + lane * 1040, wB = (u32)(size_t)&ringB[0] + lane * 1040;
+    const u32 haddr = lane == 0 ? (u32)(size_t)&halo[0] : (u32)(size_t)&lowv[0];
+    const u32 hstep = lane == 0 ? 256u : 0u;   // lane 0 walks the halo array, the others keep reading the low values
+    const unsigned char* cp = a.codes + 128 - 63;          // + (63 - lane) + u
+    const u32 voff = 63u - (u32)lane;
+    const int gA1 = a.init[5 * lane], gB1 = a.init[5 * lane + 1], tA = a.init[5 * lane + 2], tB = a.init[5 * lane + 3], z0 = a.init[5 * lane + 4];
+    const u32 expoff = lane == 63 ? 0u : 0xFFFFFF00u;
+    const uint64_t eb = (uint64_t)(uintptr_t)a.edge;
+    u64 r0 = now_rt();
+    u64 t0 = now();
+    asm volatile(
+        "v_mov_b32 v79, %[ga1]\n\t"
+        "v_mov_b32 v95, %[gb1]\n\t"
+        "v_mov_b32 v117, %[ta]\n\t"
+        "v_mov_b32 v119, %[tb]\n\t"
+        "v_mov_b32 v121, %[z0]\n\t"
+        // lane 0 of every gA register is never written by the DPP op: give it the lane's constant once
+        "v_mov_b32 v64, %[ga1]\n\tv_mov_b32 v65, %[ga1]\n\tv_mov_b32 v66, %[ga1]\n\tv_mov_b32 v67, %[ga1]\n\t"
+        "v_mov_b32 v68, %[ga1]\n\tv_mov_b32 v69, %[ga1]\n\tv_mov_b32 v70, %[ga1]\n\tv_mov_b32 v71, %[ga1]\n\t"
+        "v_mov_b32 v72, %[ga1]\n\tv_mov_b32 v73, %[ga1]\n\tv_mov_b32 v74, %[ga1]\n\tv_mov_b32 v75, %[ga1]\n\t"
+        "v_mov_b32 v76, %[ga1]\n\tv_mov_b32 v77, %[ga1]\n\tv_mov_b32 v78, %[ga1]\n\t"
+        "s_mov_b64 s[92:93], %[cp]\n\t"
+        "s_mov_b32 s88, %[nch]\n\t"
+        "s_mov_b32 s90, 0\n\t"
+        "s_mov_b32 s75, 0\n\t"
+        "s_mov_b32 s76, %[e0]\n\t"
+        "s_mov_b32 s77, %[e1]\n\t"
+        "s_mov_b32 s78, 0x7FFFFF00\n\t"
+        "s_mov_b32 s79, 0x00020000\n\t"
+        "v_mov_b32 v96, %[voff]\n\t"
+        "v_mov_b32 v97, %[expoff]\n\t"
+        "v_mov_b32 v98, %[haddr]\n\t"
+        "v_mov_b32 v99, %[wa]\n\t"
+        "v_mov_b32 v123, %[wb]\n\t"
+        // codes of blocks 0 and 1 (A' stream at step offset +1, B stream one further)
+        "global_load_dwordx4 v[48:51], v96, s[92:93] offset:1\n\t"
+        "global_load_dwordx4 v[52:55], v96, s[92:93] offset:2\n\t"
+        "global_load_dwordx4 v[56:59], v96, s[92:93] offset:17\n\t"
+        "global_load_dwordx4 v[60:63], v96, s[92:93] offset:18\n\t"
+        // halo groups of block 0
+        "ds_read_b128 v[100:103], v98 offset:0\n\t"
+        "ds_read_b128 v[104:107], v98 offset:16\n\t"
+        "ds_read_b128 v[108:111], v98 offset:32\n\t"
+        "ds_read_b128 v[112:115], v98 offset:48\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+        "Lchunk_%=:\n\t"
+        BLOCK("v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[48:51]", "v[52:55]", "33", "34", "0", "16", "32", "48", "64", "80", "96", "112")
+        BLOCK("v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v[56:59]", "v[60:63]", "49", "50", "64", "80", "96", "112", "128", "144", "160", "176")
+        BLOCK("v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v[48:51]", "v[52:55]", "65", "66", "128", "144", "160", "176", "192", "208", "224", "240")
+        BLOCK("v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v[56:59]", "v[60:63]", "81", "82", "192", "208", "224", "240", "256", "272", "288", "304")
+        "v_add_u32 v98, %[hstep], v98\n\t"
+        "s_add_i32 s90, s90, 256\n\t"
+        "s_and_b32 s90, s90, 1023\n\t"
+        "v_add_u32 v99, s90, %[wa]\n\t"
+        "v_add_u32 v123, s90, %[wb]\n\t"
+        "s_add_i32 s75, s75, 256\n\t"
+        "s_add_u32 s92, s92, 64\n\t"
+        "s_addc_u32 s93, s93, 0\n\t"
+        "s_add_i32 s88, s88, -1\n\t"
+        "s_cmp_gt_i32 s88, 0\n\t"
+        "s_cbranch_scc1 Lchunk_%=\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        :
+        : [ga1] "v"(gA1), [gb1] "v"(gB1), [ta] "v"(tA), [tb] "v"(tB), [z0] "v"(z0), [cp] "s"(cp), [nch] "s"(a.nchunks), [voff] "v"(voff),
+          [expoff] "v"(expoff), [haddr] "v"(haddr), [hstep] "v"(hstep), [wa] "v"(wA), [wb] "v"(wB), [palo] "v"(palo), [pahi] "v"(pahi),
+          [pblo] "v"(pblo), [pbhi] "v"(pbhi), [ngap] "v"(ngap), [e0] "s"((u32)eb), [e1] "s"((u32)(eb >> 32))
+        : "vcc", "scc", "memory", "s75", "s76", "s77", "s78", "s79", "s88", "s90", "s92", "s93", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47",
+          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68",
+          "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89",
+          "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",
+          "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123");
+    u64 t1 = now();
+    u64 r1 = now_rt();
+    __syncthreads();
+    if (VERIFY) {
+        const int nsteps = a.nchunks * 64;
+        for (int u = 1; u <= nsteps && u <= 256; ++u) {
+            a.outA[(u - 1) * 64 + lane] = ringA[lane * 260 + ((u - 1) & 255)];
+            a.outB[(u - 1) * 64 + lane] = ringB[lane * 260 + ((u - 1) & 255)];
+        }
+    }
+    if (lane == 0) { a.clk[0] = t1 - t0; a.clk[1] = r1 - r0; }
+}
+
+int main() {
+    const int nch_v = 4, nsteps = nch_v * 64;
+    srand(4711);
+    const int OFF = 128;
+    std::vector<unsigned char> codes(OFF + 64 * 1100 + 512);
+    for (auto& c : codes) c = rand() % 8;
+    std::vector<int> halo(1024 + 128), init(64 * 5), edge(64 * 1100 + 1024);
+    std::vector<u32> prof(64 * 4);
+    static signed char pa[64][8], pb[64][8];
+    auto pack = [](signed char* p, int o) { return (u32)(unsigned char)p[o] | ((u32)(unsigned char)p[o + 1] << 8) | ((u32)(unsigned char)p[o + 2] << 16) | ((u32)(unsigned char)p[o + 3] << 24); };
+    for (int l = 0; l < 64; ++l) {
+        for (int c = 0; c < 8; ++c) { pa[l][c] = (signed char)((rand() % 40) - 30); pb[l][c] = (signed char)((rand() % 40) - 30); }
+        pa[l][7] = pb[l][7] = -100;
+        prof[4 * l] = pack(pa[l], 0); prof[4 * l + 1] = pack(pa[l], 4); prof[4 * l + 2] = pack(pb[l], 0); prof[4 * l + 3] = pack(pb[l], 4);
+    }
+    const int ngap = 2, bias = (int)0x95010000u;   // a launch tag >= 0x80: every G is negative as int32
+    const int low = bias;
+    int hv = bias + 300;
+    for (size_t i = 0; i < halo.size(); ++i) { hv += rand() % 4; halo[i] = hv; }
+    std::vector<int> gA(64), gB(64), tA(64), tB(64), Z(64);
+    for (int l = 0; l < 64; ++l) {
+        gA[l] = (l == 0) ? bias : bias + 40 + 4 * l + rand() % 3;
+        gB[l] = (l == 0) ? bias + 290 : gA[l] + 2 + rand() % 2;
+        tA[l] = gA[l] - 100; tB[l] = gB[l] - 100;
+        Z[l] = bias + 10 + ngap * l;          // before the first step's add
+        init[5 * l] = gA[l]; init[5 * l + 1] = gB[l]; init[5 * l + 2] = tA[l]; init[5 * l + 3] = tB[l]; init[5 * l + 4] = Z[l];
+    }
+    // host restatement
+    std::vector<std::vector<int>> wantA(nsteps + 1, std::vector<int>(64)), wantB(nsteps + 1, std::vector<int>(64));
+    {
+        std::vector<int> a1 = gA, b1 = gB, ta = tA, tb = tB, z = Z;
+        for (int u = 1; u <= nsteps; ++u) {
+            std::vector<int> P(64), na(64), nb(64), nta(64), ntb(64);
+            for (int l = 0; l < 64; ++l) { z[l] += ngap; P[l] = std::max(std::max(tb[l], b1[l]), z[l]); }
+            for (int l = 0; l < 64; ++l) {
+                const int Q = std::max(std::max(ta[l], b1[l]), z[l]);
+                ntb[l] = b1[l] + pa[l][codes[OFF + u - l]];
+                na[l] = (l == 0) ? a1[l] : std::max(P[l - 1], a1[l]);
+                nb[l] = std::max(std::max(Q, na[l]), l == 0 ? halo[u - 1] : low);
+                nta[l] = na[l] + pb[l][codes[OFF + 1 + u - l]];
+            }
+            a1 = na; b1 = nb; ta = nta; tb = ntb;
+            wantA[u] = na; wantB[u] = nb;
+        }
+    }
+    unsigned char* d_codes; int *d_halo, *d_init, *d_edge, *d_outA, *d_outB; u32* d_prof; u64* d_clk;
+    hipMalloc(&d_codes, codes.size()); hipMalloc(&d_halo, halo.size() * 4); hipMalloc(&d_init, init.size() * 4); hipMalloc(&d_edge, edge.size() * 4);
+    hipMalloc(&d_prof, prof.size() * 4); hipMalloc(&d_outA, nsteps * 64 * 4); hipMalloc(&d_outB, nsteps * 64 * 4); hipMalloc(&d_clk, 64);
+    hipMemcpy(d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice);
+    hipMemcpy(d_halo, halo.data(), halo.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_init, init.data(), init.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_prof, prof.data(), prof.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(d_edge, 0, edge.size() * 4);
+    Args a = {d_codes, d_halo, d_init, d_prof, d_edge, ngap, low, nch_v, d_outA, d_outB, d_clk};
+    hipLaunchKernelGGL(perm2_k<1>, dim3(1), dim3(64), 0, 0, a);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 1; }
+    std::vector<int> oA(nsteps * 64), oB(nsteps * 64);
+    hipMemcpy(oA.data(), d_outA, oA.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(oB.data(), d_outB, oB.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(edge.data(), d_edge, edge.size() * 4, hipMemcpyDeviceToHost);
+    int bad = 0;
+#ifndef NO_RING
+    for (int u = 1; u <= nsteps; ++u)
+        for (int l = 0; l < 64; ++l) {
+            if (l > 0 && oA[(u - 1) * 64 + l] != wantA[u][l]) { if (bad < 10) printf("MISMATCH A step %d lane %d: got %d want %d\n", u, l, oA[(u - 1) * 64 + l] - bias, wantA[u][l] - bias); ++bad; }
+            if (oB[(u - 1) * 64 + l] != wantB[u][l]) { if (bad < 10) printf("MISMATCH B step %d lane %d: got %d want %d\n", u, l, oB[(u - 1) * 64 + l] - bias, wantB[u][l] - bias); ++bad; }
+        }
+#endif
+#ifndef NO_EXPORT
+    for (int u = 1; u <= nsteps; ++u)
+        if (edge[u - 1] != wantB[u][63]) { if (bad < 10) printf("MISMATCH edge step %d: got %d want %d\n", u, edge[u - 1] - bias, wantB[u][63] - bias); ++bad; }
+#endif
+    printf("verify: %s (%d steps x 64 lanes x 2 columns, edge column)\n", bad ? "FAILED" : "ok", nsteps);
+    for (int rep = 0; rep < 3; ++rep) {
+        a.nchunks = 15;
+        hipLaunchKernelGGL(perm2_k<0>, dim3(1), dim3(64), 0, 0, a);
+        hipDeviceSynchronize();
+        u64 c[2]; hipMemcpy(c, d_clk, 16, hipMemcpyDeviceToHost);
+        printf("two-column producer (7 VALU/step for 2 cells + 8 perm/16 + 2 ring writes + edge store + halo read per 4 steps): %.1f clk/step, %.2f ns/step "
+               "(s_memtime at %.0f MHz)\n", (double)c[0] / (15 * 64.0), (double)c[1] * 10.0 / (15 * 64.0), (double)c[0] / ((double)c[1] * 0.01));
+    }
+    return bad ? 1 : 0;
+}
