@@ -103,6 +103,9 @@ def chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows):
     eng.fill_into(out, d_a, d_b)
     eng.synchronize()
     eng.set_option("debug_buf", 0)
+    S2 = int(eng.get_option("last_strips2"))   # > 0: the two-column kernel ran (126 columns per strip)
+    if S2 > 0:
+        S = S2
     t = dbg.cpu().numpy()[:2 * S].reshape(S, 2).astype(np.float64) * 10.0   # 100 MHz ticks -> ns
     steps = rows + 63 + (S - 1)
     tau = (t[0, 1] - t[0, 0]) / max(1, steps)

@@ -62,6 +62,7 @@ struct sw_ctx {
     int64_t opt_waves_per_block = 4;
     int64_t opt_max_blocks = 0;         // 0 -> 2 * CUs
     int64_t last_grid = 0, last_strips = 0;
+    int64_t last_strips2 = 0;           // strips of the two-column kernel in the last launch (0: not launched)
     std::map<void*, void*> out_base;    // sw_alloc_outputs: pointer handed out -> allocation to free
 };
 
@@ -142,6 +143,7 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "debug_edge4_cap")) return (int64_t)c->edge4_cap;
     if (!strcmp(name, "last_grid")) return c->last_grid;
     if (!strcmp(name, "last_strips")) return c->last_strips;
+    if (!strcmp(name, "last_strips2")) return c->last_strips2;
     return -1;
 }
 
@@ -340,6 +342,35 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         }
         const unsigned char* cbp = c->d_cb;
         bool launched = false;
+        c->last_strips2 = 0;
+        // Two matrix columns per lane (sw_systolic2.inc): half as many strips -- and row segments of 504 bytes per store -- for the
+        // same work: 16384^2 +4 %, 8192^2 +11 %, 24576^2 +29 %, 32768^2 +32 %, 65536^2 +9 % over one column per lane.  Whole
+        // matrix of one pair, int32 H and P both stored, rows a multiple of 16; the alphabet (found on the device) must allow the
+        // perm path -- so both kernels are enqueued and each checks for itself which of them has to work.  (debug bit 14: off)
+        const bool two_cols = perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 && j.d_H && j.d_P &&
+                              j.h_elem_bytes == 4 && j.p_elem_bytes == 4 && !j.d_top && !j.d_left && !j.d_right && !j.d_top_gran && !j.d_bot_gran &&
+                              j.stride == cols + 1 && rows % 16 == 0 && rows >= 16 && cols >= 2 && !(c->opt_debug & (1 | 2 | 8 | 64 | 128 | 512 | 16384));
+        if (two_cols) {
+            const int64_t S2 = (cols + 125) / 126;
+            swk::FillParams p2 = p;
+            p2.nstrips = (int)S2;
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, swk::sw_systolic2<6>, 768, 0));
+            if (per_cu >= 1) {
+                const int grid2 = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S2, maxb), (int64_t)per_cu * c->num_cus));
+                HIP_TRY(hipMemsetAsync(j.d_H, 0, (size_t)(cols + 1) * 4, stream));      // row 0
+                HIP_TRY(hipMemsetAsync(j.d_P, 0, (size_t)(cols + 1) * 4, stream));
+                hipLaunchKernelGGL(swk::sw_zero_col0, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, stream, (int32_t*)j.d_H, (int32_t*)j.d_P,
+                                   cols + 1, rows + 1);
+                const int nc2 = c->opt_consumers == 0 ? (chain_bound ? 5 : 6) : (int)std::min<int64_t>(7, c->opt_consumers);   // + 9 - nc2 importers
+                if (nc2 == 7) hipLaunchKernelGGL(swk::sw_systolic2<7>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
+                else if (nc2 == 6) hipLaunchKernelGGL(swk::sw_systolic2<6>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
+                else if (nc2 == 5) hipLaunchKernelGGL(swk::sw_systolic2<5>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
+                else hipLaunchKernelGGL(swk::sw_systolic2<4>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
+                p.skip_if_perm = 1;
+                c->last_strips2 = S2;
+            }
+        }
         // every workgroup of the grid must be resident (they wait for each other): never launch more than the occupancy
         // query admits on this device
 #define SW_LAUNCH(ns, nc)                                                                                                        \

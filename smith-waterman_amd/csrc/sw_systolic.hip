@@ -1061,6 +1061,7 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
     // perm producer: eligible on the host side (score range -> gbias != 0) AND an alphabet of at most 7 letters (found on
     // the device by sw_pad_b); it always uses the fast step numbering
     const bool perm = (p.gbias != 0) && (*(const unsigned int*)(p.atab + 256) <= 7u) && !(p.debug_flags & 16);
+    if (perm && p.skip_if_perm) return;   // the two-column kernel (sw_systolic2.inc), launched right before this one, has done the fill
     const int phib = perm ? p.nstrips - 1 : p.phi_base;
     const int gb = perm ? (int)p.gbias : 0;       // carried by every G value
     const int ugran = perm ? 64 : SY_U;   // the perm producer tests for the end once per 64-step chunk
@@ -1845,5 +1846,12 @@ __global__ void __launch_bounds__(256) sw_pad_b(const unsigned char* __restrict_
         bcode[pair * per + i] = in ? tab[ch] : (unsigned char)7;
     }
 }
+
+__global__ void sw_zero_col0(int32_t* H, int32_t* P, int64_t M, int64_t rows1) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows1) { H[r * M] = 0; P[r * M] = 0; }
+}
+
+#include "sw_systolic2.inc"
 
 }  // namespace swk
