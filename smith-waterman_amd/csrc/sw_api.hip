@@ -349,7 +349,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         // perm path -- so both kernels are enqueued and each checks for itself which of them has to work.  (debug bit 14: off)
         const bool two_cols = perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 && j.d_H && j.d_P &&
                               j.h_elem_bytes == 4 && j.p_elem_bytes == 4 && !j.d_top && !j.d_left && !j.d_right && !j.d_top_gran && !j.d_bot_gran &&
-                              j.stride == cols + 1 && rows % 16 == 0 && rows >= 16 && cols >= 2 && !(c->opt_debug & (1 | 2 | 8 | 64 | 128 | 512 | 16384));
+                              j.stride == cols + 1 && rows % 16 == 0 && rows >= 16 && cols >= 1 && !(c->opt_debug & (1 | 2 | 8 | 64 | 128 | 512 | 16384));
         if (two_cols) {
             const int64_t S2 = (cols + 125) / 126;
             swk::FillParams p2 = p;

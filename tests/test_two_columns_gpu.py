@@ -1,0 +1,78 @@
+"""GPU: the two-columns-per-lane fill kernel (sw_systolic2.inc) -- selected by the library for whole-matrix fills of one pair
+with int32 H and P and rows % 16 == 0 -- against the oracle, bit-exact, and against the one-column kernel (debug bit 14)."""
+import numpy as np
+import pytest
+
+from test_fill_gpu import check_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+# strips are 126 columns wide: single strip, one column over, odd column counts (the last strip then has a lane that owns only
+# its A column), many strips; rows: one block, several, not a multiple of the ring length
+SHAPES = [(1, 16), (2, 16), (3, 32), (125, 48), (126, 16), (127, 160), (251, 64), (252, 64), (253, 80), (1000, 704), (1007, 304),
+          (4000, 1296), (5001, 528)]
+
+
+@pytest.mark.parametrize("cols,rows", SHAPES)
+def test_two_column_kernel_matches_oracle(engine, oracle, cols, rows):
+    a, b = oracle.generate(cols, rows, 77)
+    check_against_oracle(engine, oracle, a, b)
+    assert engine.get_option("last_strips2") == (cols + 125) // 126, "the two-column kernel was expected to run"
+
+
+def test_rows_not_a_multiple_of_16_fall_back(engine, oracle):
+    a, b = oracle.generate(500, 250, 78)
+    check_against_oracle(engine, oracle, a, b)
+    assert engine.get_option("last_strips2") == 0
+
+
+@pytest.mark.parametrize("scores", [(5, -3, -4), (3, -3, 0), (2, 1, -3), (1, -1, -1)], ids=str)
+def test_other_scorings(engine, oracle, scores):
+    a, b = oracle.generate(700, 400, 79)
+    check_against_oracle(engine, oracle, a, b, scores)
+    assert engine.get_option("last_strips2") > 0
+
+
+def test_same_results_as_the_one_column_kernel_and_more_passes_than_cus(engine, oracle):
+    import torch
+    a, b = oracle.generate(9000, 1600, 80)          # 72 strips
+    engine.set_option("max_blocks", 7)              # 11 passes of the strip loop per workgroup
+    try:
+        two = engine.fill(a, b)
+        assert engine.get_option("last_strips2") == 72
+        engine.set_option("debug_flags", 16384)
+        one = engine.fill(a, b)
+        assert engine.get_option("last_strips2") == 0
+    finally:
+        engine.set_option("debug_flags", 0)
+        engine.set_option("max_blocks", 0)
+    assert torch.equal(two.H, one.H) and torch.equal(two.P, one.P) and two.result() == one.result()
+    H, P, mp = oracle.fill(a, b)
+    assert np.array_equal(two.H.cpu().numpy(), H) and np.array_equal(two.P.cpu().numpy(), P) and two.result()["max_pos"] == mp
+
+
+def test_other_alphabets_and_ties(engine, oracle):
+    rng = np.random.default_rng(5)
+    for letters in (b"AC", b"ACGTN", b"xyzwvut"):
+        a = rng.choice(np.frombuffer(letters, np.uint8), size=900).astype(np.uint8)
+        b = rng.choice(np.frombuffer(letters, np.uint8), size=320).astype(np.uint8)
+        check_against_oracle(engine, oracle, a, b)
+        assert engine.get_option("last_strips2") > 0
+    a = np.frombuffer(b"ACGT" * 200, np.uint8).copy()      # periodic: many cells share the maximum, the lowest index must win
+    check_against_oracle(engine, oracle, a, a[:320].copy())
+    eight = rng.choice(np.frombuffer(b"ABCDEFGH", np.uint8), size=640).astype(np.uint8)   # 8 letters: the one-column kernel's job
+    check_against_oracle(engine, oracle, eight, eight[:160].copy())
+    assert engine.get_option("last_strips2") > 0      # (launched, and left at once: the alphabet is only known on the device)
+
+
+def test_more_strips_than_cus_streaming_checksums(engine, oracle, swamd):
+    """40000 x 4096: 318 strips of 126 columns, i.e. a second pass of the strip loop on a 256-CU device; per-row checksums and
+    arg-max against the streaming oracle."""
+    a, b = swamd.generate(40000, 4096, 3)
+    st = oracle.fill_streaming(a, b)
+    out = engine.fill(a, b)
+    assert engine.get_option("last_strips2") == 318
+    r = out.result()
+    assert r["max_pos"] == st["max_pos"] and r["max_score"] == st["max_score"]
+    assert np.array_equal(engine.row_checksums(out.H), st["csH"]) and np.array_equal(engine.row_checksums(out.P), st["csP"])
+    assert np.array_equal(out.H[-1].cpu().numpy(), st["bottom"])
