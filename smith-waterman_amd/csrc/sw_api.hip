@@ -347,9 +347,12 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         // same work: 16384^2 +4 %, 8192^2 +11 %, 24576^2 +29 %, 32768^2 +32 %, 65536^2 +9 % over one column per lane.  Whole
         // matrix of one pair, int32 H and P both stored, rows a multiple of 16; the alphabet (found on the device) must allow the
         // perm path -- so both kernels are enqueued and each checks for itself which of them has to work.  (debug bit 14: off)
-        const bool two_cols = perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 && j.d_H && j.d_P &&
-                              j.h_elem_bytes == 4 && j.p_elem_bytes == 4 && !j.d_top && !j.d_left && !j.d_right && !j.d_top_gran && !j.d_bot_gran &&
-                              j.stride == cols + 1 && rows % 16 == 0 && rows >= 16 && cols >= 1 && !(c->opt_debug & (1 | 2 | 8 | 64 | 128 | 512 | 16384));
+        // Also: int8 P, either matrix left out, and band-resident launches (halo row in, last row out as granules).
+        const bool base_mode = j.d_H && j.d_P && j.p_elem_bytes == 4 && !j.d_top && !j.d_top_gran && !j.d_bot_gran;   // int32 H + P, whole matrix
+        const bool two_cols = perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 &&
+                              j.h_elem_bytes == 4 && !j.d_left && !j.d_right && j.stride == cols + 1 && rows % 16 == 0 && rows >= 16 && cols >= 1 &&
+                              (base_mode || (cols % 2 == 0)) &&   // (an odd column count leaves one lane with a single column: only the base mode handles it)
+                              !(c->opt_debug & (1 | 2 | 8 | 64 | 128 | 512 | 16384));
         if (two_cols) {
             const int64_t S2 = (cols + 125) / 126;
             swk::FillParams p2 = p;
@@ -358,10 +361,15 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, swk::sw_systolic2<6>, 768, 0));
             if (per_cu >= 1) {
                 const int grid2 = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S2, maxb), (int64_t)per_cu * c->num_cus));
-                HIP_TRY(hipMemsetAsync(j.d_H, 0, (size_t)(cols + 1) * 4, stream));      // row 0
-                HIP_TRY(hipMemsetAsync(j.d_P, 0, (size_t)(cols + 1) * 4, stream));
-                hipLaunchKernelGGL(swk::sw_zero_col0, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, stream, (int32_t*)j.d_H, (int32_t*)j.d_P,
-                                   cols + 1, rows + 1);
+                // row 0 and column 0 are not the kernel's: zeros, except a band's halo row (its H comes from the row above, written by
+                // the kernel; its P belongs to the band above)
+                const bool has_top = j.d_top || j.d_top_gran;
+                if (!has_top) {
+                    if (j.d_H) HIP_TRY(hipMemsetAsync(j.d_H, 0, (size_t)(cols + 1) * 4, stream));
+                    if (j.d_P) HIP_TRY(hipMemsetAsync(j.d_P, 0, (size_t)(cols + 1) * (size_t)j.p_elem_bytes, stream));
+                }
+                hipLaunchKernelGGL(swk::sw_zero_col0, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, stream, (int32_t*)j.d_H, j.d_P,
+                                   j.p_elem_bytes, cols + 1, rows + 1, has_top ? 1 : 0);
                 const int nc2 = c->opt_consumers == 0 ? (chain_bound ? 5 : 6) : (int)std::min<int64_t>(7, c->opt_consumers);   // + 9 - nc2 importers
                 if (nc2 == 7) hipLaunchKernelGGL(swk::sw_systolic2<7>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
                 else if (nc2 == 6) hipLaunchKernelGGL(swk::sw_systolic2<6>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
@@ -371,8 +379,6 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 c->last_strips2 = S2;
             }
         }
-        // every workgroup of the grid must be resident (they wait for each other): never launch more than the occupancy
-        // query admits on this device
 #define SW_LAUNCH(ns, nc)                                                                                                        \
     if (!launched && NS == ns && NC == nc) {                                                                                      \
         launched = true;                                                                                                          \

@@ -62,7 +62,7 @@ __global__ void sw_systolic(const unsigned char* a, const unsigned char* b, cons
 __global__ void sw_wipe_u32(unsigned int* buf, size_t n);
 template <int NC>
 __global__ void sw_systolic2(const unsigned char* a, const unsigned char* b, FillParams p);
-__global__ void sw_zero_col0(int32_t* H, int32_t* P, int64_t M, int64_t rows1);
+__global__ void sw_zero_col0(int32_t* H, void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0);
 __global__ void sw_alpha_scan(const unsigned char* a, int64_t cols, int64_t a_pstride, const unsigned char* b, int64_t rows, int64_t b_pstride,
                               int64_t npairs, unsigned int* present);
 __global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, int64_t b_pstride, unsigned char* bpad, unsigned short* bpad16,

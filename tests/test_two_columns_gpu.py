@@ -76,3 +76,48 @@ def test_more_strips_than_cus_streaming_checksums(engine, oracle, swamd):
     assert r["max_pos"] == st["max_pos"] and r["max_score"] == st["max_score"]
     assert np.array_equal(engine.row_checksums(out.H), st["csH"]) and np.array_equal(engine.row_checksums(out.P), st["csP"])
     assert np.array_equal(out.H[-1].cpu().numpy(), st["bottom"])
+
+
+@pytest.mark.parametrize("mode", ["p8", "p8_only", "p32_only", "h_only", "score_only"])
+@pytest.mark.parametrize("cols,rows", [(1000, 704), (2520, 320), (126, 16)])
+def test_output_modes(engine, oracle, cols, rows, mode):
+    """int8 P, either matrix left out, score only: exact arg-max in every mode (without H the block statement records the cell)."""
+    import torch
+    a, b = oracle.generate(cols, rows, 81)
+    H, P, mp = oracle.fill(a, b)
+    want_h = mode in ("p8", "h_only")
+    want_p = mode in ("p8", "p8_only", "p32_only")
+    out = engine.fill(a, b, p_dtype=torch.int8 if mode.startswith("p8") else None, want_h=want_h, want_p=want_p)
+    assert engine.get_option("last_strips2") == (cols + 125) // 126
+    r = out.result()
+    assert r["max_pos"] == mp and r["max_score"] == int(H.flat[mp])
+    if want_h:
+        assert np.array_equal(out.H.cpu().numpy(), H)
+    if want_p:
+        assert np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
+        path = engine.traceback(out, mp)
+        P1 = P.copy()
+        assert np.array_equal(path, oracle.backtrack(P1, mp)) and np.array_equal(out.P.cpu().numpy().astype(np.int32), P1)
+
+
+def test_argmax_ties_without_h_two_columns(engine, oracle):
+    for a, b in ((b"ACGT" * 80, b"ACGT" * 72), (b"A" * 300, b"A" * 208), (b"AC" * 150, b"CA" * 104)):
+        H, P, mp = oracle.fill(a, b)
+        r = engine.fill(a, b, want_h=False, want_p=False).result()
+        assert engine.get_option("last_strips2") > 0
+        assert r["max_pos"] == mp and r["max_score"] == int(H.flat[mp])
+
+
+@pytest.mark.parametrize("cols,rows,cuts,p8,want_h", [(1000, 640, (320,), False, True), (4200, 1296, (416, 880), False, True),
+                                                     (1500, 912, (304, 608), True, False), (252, 96, (16, 32, 48, 64), True, True)])
+def test_band_resident_launches_on_the_two_column_kernel(engine, oracle, swamd, cols, rows, cuts, p8, want_h):
+    """Stacked bands whose heights are multiples of 16: halo row in and last row out as granules, per-63-column-strip flags."""
+    from test_band_gpu import _bands
+    _bands(engine, oracle, swamd, cols, rows, cuts, p8=p8, want_h=want_h)
+    assert engine.get_option("last_strips2") == (cols + 125) // 126
+
+
+def test_lower_band_first_on_the_two_column_kernel(engine, oracle, swamd):
+    from test_band_gpu import _bands
+    ncu = engine.get_option("num_cus")
+    _bands(engine, oracle, swamd, 5000, 2016, (1008,), reverse=True, max_blocks=max(8, ncu // 2 - 8))
