@@ -20,16 +20,23 @@ step smoke 300 python __graft_entry__.py smoke
 step pytest_gpu 900 python -m pytest tests -m gpu -x -q
 step bench 600 python bench.py
 step bench_first_alloc 300 python bench.py --steps 10 --warmup 2 --no-cpu --placement-trials 1
+step bench_one_column 300 python bench.py --steps 20 --warmup 3 --no-cpu --debug-flags 16384
 step bench_old_producers 300 python bench.py --steps 10 --warmup 2 --no-cpu --debug-flags 16
 step bench_strip_scan 200 python bench.py --steps 5 --warmup 1 --no-cpu --engine 1 --placement-trials 1
 step bench_h64_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64
 step bench_h64_64k_first_alloc 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64 --placement-trials 1
 step bench_i32_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536
 step bench_i32_64k_first_alloc 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --placement-trials 1
+step bench_i32_64k_one_column 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --debug-flags 16384
+step bench_i32_32k 400 python bench.py --steps 5 --warmup 2 --no-cpu --cols 32768 --rows 32768
+step bench_i32_32k_one_column 400 python bench.py --steps 5 --warmup 2 --no-cpu --cols 32768 --rows 32768 --debug-flags 16384
+step bench_i32_8k 300 python bench.py --steps 10 --warmup 3 --no-cpu --cols 8192 --rows 8192
+step bench_i32_8k_one_column 300 python bench.py --steps 10 --warmup 3 --no-cpu --cols 8192 --rows 8192 --debug-flags 16384
 step bench_p8 300 python bench.py --steps 10 --warmup 2 --no-cpu --p8
 step bench_bands_1gpu_16k 300 python bench.py --mode bands --cols 16384 --rows 16384 --steps 10 --warmup 2
 step bench_bands_1gpu_128k_p8 600 python bench.py --mode bands --cols 131072 --rows 131072 --steps 2 --warmup 1 --p8
 step bench_band_n8_shape_p8 600 python bench.py --mode bands --cols 262144 --rows 32768 --steps 3 --warmup 1 --p8
+step bench_band_n8_shape_p8_one_column 600 python bench.py --mode bands --cols 262144 --rows 32768 --steps 3 --warmup 1 --p8 --debug-flags 16384
 step bench_config4_one_gpu_p_only 600 python bench.py --mode bands --cols 262144 --rows 262144 --p8 --no-h --steps 2 --warmup 1
 step bench_rehearsal_2ranks_gloo_1gpu 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --cols 32768 --rows 32768
 step cli_16384 300 ./smith-waterman_amd/smithW 16384 16384

@@ -349,7 +349,13 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         // perm path -- so both kernels are enqueued and each checks for itself which of them has to work.  (debug bit 14: off)
         // Also: int8 P, either matrix left out, and band-resident launches (halo row in, last row out as granules).
         const bool base_mode = j.d_H && j.d_P && j.p_elem_bytes == 4 && !j.d_top && !j.d_top_gran && !j.d_bot_gran;   // int32 H + P, whole matrix
-        const bool two_cols = perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 &&
+        // Where it pays: always for int32 H + P (8-byte stores of both matrices); in the other output formats while the strip chain
+        // (~3.1 us per 63-column strip) rather than the output volume (~3.2 TB/s) bounds the fill -- measured: 262144 x 32768 with
+        // int8 P +18 %, 131072^2 with int8 P -3 %, 262144^2 P-only -21 % (two byte stores per row and the in-block arg-max).
+        const double est_chain = (double)S * 3.1e-6;
+        const double est_hbm = (double)(cols + 1) * (double)(rows + 1) * ((j.d_H ? 4.0 : 0.0) + (j.d_P ? (double)j.p_elem_bytes : 0.0)) / 3.2e12;
+        const bool pays = (j.d_H && j.d_P && j.p_elem_bytes == 4) || est_chain >= (j.d_H ? 0.5 : 2.0) * est_hbm || (c->opt_debug & 32768);
+        const bool two_cols = pays && perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 &&
                               j.h_elem_bytes == 4 && !j.d_left && !j.d_right && j.stride == cols + 1 && rows % 16 == 0 && rows >= 16 && cols >= 1 &&
                               (base_mode || (cols % 2 == 0)) &&   // (an odd column count leaves one lane with a single column: only the base mode handles it)
                               !(c->opt_debug & (1 | 2 | 8 | 64 | 128 | 512 | 16384));
@@ -652,6 +658,7 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
     const size_t phase = 4u << 20;
     struct Cand { void* H; void* Pbase; void* P; void* spacer; float ms; };
     std::vector<Cand> cands;
+    std::vector<void*> Hs;
     sw_result* d_res = nullptr;
     if (hipMalloc((void**)&d_res, sizeof(sw_result)) != hipSuccess) { set_err("sw_alloc_outputs: allocation failed"); return SW_ENOMEM; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -660,8 +667,14 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
     int best = -1, rc = SW_OK;
     for (int i = 0; i < trials; ++i) {
         Cand k = {nullptr, nullptr, nullptr, nullptr, 0.f};
-        if (i > 0) k.H = cands[0].H;   // H stays where it is; the candidates differ in where P lands
-        else if (hipMalloc(&k.H, hbytes ? hbytes : 1) != hipSuccess) { (void)hipGetLastError(); break; }
+        // H stays where it is and the candidates differ in where P lands; half way through a second H is tried as well
+        if (i == 0 || (i == trials / 2 && trials >= 6 && hbytes < (8ull << 30))) {
+            void* h = nullptr;
+            if (hipMalloc(&h, hbytes ? hbytes : 1) != hipSuccess) { (void)hipGetLastError(); if (i == 0) break; }
+            else Hs.push_back(h);
+        }
+        if (Hs.empty()) break;
+        k.H = Hs.back();
         // Measured (scripts/ab_arena.py, profiles/r02_placement_arena.log): inside one 96 GiB allocation a 16384^2 fill takes
         // 1.12 ms when H and P lie on different sides of the 64 GiB mark and 1.38-1.47 ms when they share a side, whatever
         // their distance.  So from the second candidate on a spacer of 64 GiB (then 32, 96, 48, 80) is allocated between
@@ -674,7 +687,7 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
         }
         if (sp && hipMalloc(&k.spacer, sp) == hipSuccess) spacer_total += sp;
         else { (void)hipGetLastError(); k.spacer = nullptr; }
-        if (hipMalloc(&k.Pbase, pbytes + phase) != hipSuccess) { (void)hipGetLastError(); if (i == 0) (void)hipFree(k.H); if (k.spacer) (void)hipFree(k.spacer); break; }
+        if (hipMalloc(&k.Pbase, pbytes + phase) != hipSuccess) { (void)hipGetLastError(); if (k.spacer) (void)hipFree(k.spacer); break; }
         // P two MiB out of phase with H modulo 4 MiB
         const uintptr_t want = ((uintptr_t)k.H + (2u << 20)) % phase;
         const uintptr_t off = (want + phase - ((uintptr_t)k.Pbase % phase)) % phase;
@@ -697,7 +710,8 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
         if (cands.size() >= 2) {   // clearly in the fast mode: stop looking
             float worst = 0.f;
             for (auto& x : cands) worst = std::max(worst, x.ms);
-            if (cands[best].ms < 0.9f * worst) { for (int j = i + 1; j < trials && trial_ms; ++j) trial_ms[j] = 0.f; break; }
+            if (cands[best].ms < 0.80f * worst) {   // (fast and slow mode are 20-25 % apart; the two-column kernel also has a half-good one in between)
+                for (int j = i + 1; j < trials && trial_ms; ++j) trial_ms[j] = 0.f; break; }
         }
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -706,7 +720,8 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
         if (cands[i].spacer) (void)hipFree(cands[i].spacer);
         if (i != best || rc != SW_OK) (void)hipFree(cands[i].Pbase);
     }
-    if ((best < 0 || rc != SW_OK) && !cands.empty()) (void)hipFree(cands[0].H);
+    for (void* h : Hs)
+        if (best < 0 || rc != SW_OK || h != cands[best].H) (void)hipFree(h);
     if (rc != SW_OK) return rc;
     if (best < 0) { set_err("sw_alloc_outputs: %zu + %zu bytes do not fit", hbytes, pbytes); return SW_ENOMEM; }
     *d_H = cands[best].H; *d_P = cands[best].P;
