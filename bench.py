@@ -189,13 +189,13 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
         "config": {"workload": f"{cols}x{rows} random DNA pair (reference generator, seed 1+rank), linear gap 3/-3/-2, "
                                f"{'int64' if args.h64 else 'int32'} H + {'int8' if args.p8 else 'int32'} P written to HBM, arg-max tracked",
                    "per_gpu": "one pair per GPU" + (" (replicas)" if world > 1 else ""), "max_pos": res["max_pos"], "max_score": res["max_score"],
-                   "grid": eng.get_option("last_grid"), "strips": eng.get_option("last_strips"),
+                   "grid": eng.get_option("last_grid"), "strips": int(eng.get_option("last_strips2")) or eng.get_option("last_strips"),
                    "output_buffers": "sw_alloc_outputs (C-ABI allocator, placement chosen by trial fills)" if placement_ms is not None else "plain first allocation",
                    "placement_trials_ms": placement_ms, "value_first_allocation": value_first,
                    "ms_first_allocation": sum(ms_first) / len(ms_first)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_for(key),
-                     "kernel": "sw_systolic" if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
+                     "kernel": ("sw_systolic2" if int(eng.get_option("last_strips2")) > 0 else "sw_systolic") if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
                      "algorithmic_bytes_per_cell": bytes_per_cell, "measured_contiguous_fill_GBs": fill_gbs,
                      "tau_step_ns": tau_ns, "strip_handoff_lag_ns": lag_ns,
                      "dependency_bound_gcups": (cells / ((cols + rows - 1) * tau_ns)) if tau_ns > 0 else None},
@@ -254,7 +254,8 @@ def run_bands(args, sw, eng, torch, dist, rank, world, local):
                        "mode": "bands", "max_score": score, "max_pos": pos,
                        "placement_trials_ms_rank0": [round(x, 3) for x in getattr(pipe, "placement_ms", [])]},
             "roofline": {"bound": "hbm", "achieved": achieved / world, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / world / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "sw_systolic", "algorithmic_bytes_per_cell": bpc, "per": "GPU (whole job / n_gpus)"}}
+                         "traffic": None, "kernel": "sw_systolic2" if int(eng.get_option("last_strips2")) > 0 else "sw_systolic",
+                         "algorithmic_bytes_per_cell": bpc, "per": "GPU (whole job / n_gpus)"}}
     print(json.dumps(line), flush=True)
 
 

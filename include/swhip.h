@@ -235,7 +235,9 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *   "strips_per_group"  systolic: strips (producer waves) per workgroup, 1 or 2 (0: 1 for a single pair with up to
  *                       4.5 strips per CU or a batch that fits the CUs at once, else 2)
  *   "consumers"         systolic: consumer waves per strip: 2, 3, 4; also 6, 7 with one strip per group (0: with one strip per
- *                       group 4 up to ~3.5e8 cells and 6 above, with two strips 4; 8 is taken as 7)
+ *                       group 4 up to ~3.5e8 cells and 6 above, with two strips 4; 8 is taken as 7).  The two-columns-per-lane
+ *                       kernel (whole-matrix or band fills of one pair with rows % 16 == 0; csrc/sw_systolic2.inc) takes 4..7 from
+ *                       this option (0: 5 up to ~3.5e8 cells, 6 above) and runs 9 minus that many importer waves
  *   "store_policy"      systolic H/P stores: 0 by problem size, 1 write-back, 2 streaming (nt)
  *   "importers"         systolic, one strip per workgroup: waves polling the left neighbour's edge column, besides the one that
  *                       always does (0: 4 up to ~3.5e8 cells, 2 above; at most what 12 waves per workgroup leave)

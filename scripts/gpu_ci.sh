@@ -51,10 +51,14 @@ step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_
 python3 - <<'PY' | tee gpurun_out/rocprof_timed_launches.txt
 import csv, glob
 for f in glob.glob("gpurun_out/prof/**/*kernel_trace.csv", recursive=True):
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in csv.DictReader(open(f)) if "sw_systolic" in r["Kernel_Name"]]
+    rows = list(csv.DictReader(open(f)))
+    # a fill enqueues sw_systolic2 (two columns per lane) and sw_systolic; the one that is not responsible leaves at once
+    name = "sw_systolic2" if any("sw_systolic2" in r["Kernel_Name"] for r in rows) else "sw_systolic<"
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if name in r["Kernel_Name"]]
+    idle = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if "sw_systolic<" in r["Kernel_Name"]] if name == "sw_systolic2" else []
     if len(d) >= 20:
         t = d[-21:-1]   # the last launch is the stamped one (chain_stamps); the 20 before it are the timed steps
-        print(f"{f}: {len(d)} sw_systolic launches in the trace; the 20 timed steps: avg {sum(t)/20/1e6:.4f} ms, min {min(t)/1e6:.4f}, max {max(t)/1e6:.4f}; "
-              f"all launches: avg {sum(d)/len(d)/1e6:.4f} ms")
+        print(f"{f}: {len(d)} {name} launches in the trace; the 20 timed steps: avg {sum(t)/20/1e6:.4f} ms, min {min(t)/1e6:.4f}, max {max(t)/1e6:.4f}; "
+              f"all launches: avg {sum(d)/len(d)/1e6:.4f} ms" + (f"; the {len(idle)} sw_systolic launches beside them (not responsible, leave at once): avg {sum(idle)/len(idle)/1e3:.1f} us" if idle else ""))
 PY
 for f in $(find gpurun_out/prof -name "*kernel_stats.csv"); do head -8 "$f"; done
