@@ -198,7 +198,8 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
                      "kernel": ("sw_systolic2" if int(eng.get_option("last_strips2")) > 0 else "sw_systolic") if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
                      "algorithmic_bytes_per_cell": bytes_per_cell, "measured_contiguous_fill_GBs": fill_gbs,
                      "tau_step_ns": tau_ns, "strip_handoff_lag_ns": lag_ns,
-                     "dependency_bound_gcups": (cells / ((cols + rows - 1) * tau_ns)) if tau_ns > 0 else None},
+                     # the chain of sequential steps with free hand-offs: rows + columns / (columns per lane) steps of tau each
+                     "dependency_bound_gcups": (cells / ((rows + cols / (2 if int(eng.get_option("last_strips2")) > 0 else 1) - 1) * tau_ns)) if tau_ns > 0 else None},
     }
     if not args.no_cpu and world == 1:
         cb = cpu_baseline(cols, rows)
