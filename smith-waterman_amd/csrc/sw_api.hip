@@ -358,7 +358,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         const bool two_cols = pays && perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 &&
                               j.h_elem_bytes == 4 && !j.d_left && !j.d_right && j.stride == cols + 1 && rows % 16 == 0 && rows >= 16 && cols >= 1 &&
                               (base_mode || (cols % 2 == 0)) &&   // (an odd column count leaves one lane with a single column: only the base mode handles it)
-                              !(c->opt_debug & (1 | 2 | 8 | 64 | 128 | 512 | 16384));
+                              !(c->opt_debug & (2 | 8 | 64 | 128 | 512 | 16384));
         if (two_cols) {
             const int64_t S2 = (cols + 125) / 126;
             swk::FillParams p2 = p;
