@@ -1,5 +1,6 @@
-// tools/ubench_perm2.hip -- the producer step of a strip with TWO matrix columns per lane (the next
-// round's kernel), verified against a host restatement and timed.  Lane l owns columns A = 2l-1 and B = 2l of its strip and
+// tools/ubench_perm2.hip -- the producer step of a strip with TWO matrix columns per lane (csrc/sw_systolic2.inc, DESIGN.md
+// section 5.1b), verified against a host restatement and timed (-DLATE_Z: an ordering in which no instruction uses the result
+// of the one right before it -- same 51-52 clk, i.e. the step is bound by issue, not by latencies).  Lane l owns columns A = 2l-1 and B = 2l of its strip and
 // works on the same row for both; per anti-diagonal step (7 VALU for two cells, 8 in the one-column producer):
 //     Z   += ngap                                   floor of this lane's B cell = floor of the next lane's A cell
 //     P    = max3(tB, gB1, Z)                       candidate for the NEXT lane's A cell (diagonal, left, floor)
@@ -22,6 +23,16 @@ __device__ __forceinline__ u64 now_rt() { u64 t; asm volatile("s_memrealtime %0\
 __device__ __forceinline__ u64 now() { u64 t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
 
 // gA[k] = v(64+k), gB[k] = v(80+k), Hin[k] = v(100+k); tA = v116/v117, tB = v118/v119 (alternating), P v120, Z v121, Q v122
+#ifdef LATE_Z   /* the floor of the NEXT step is formed between gA and gB: no instruction uses a result of the one right before it */
+#define S2(GA, GB, GA1, GB1, TAP, TAN, TBP, TBN, HIN, SA, SB, BYTE)                                                        \
+    "v_max3_i32 v120, " TBP ", " GB1 ", v121\n\t"                                                                         \
+    "v_max3_i32 v122, " TAP ", " GB1 ", v121\n\t"                                                                         \
+    "v_add_u32_sdwa " TBN ", " GB1 ", sext(" SA ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BYTE "\n\t" \
+    "v_max_i32_dpp " GA ", v120, " GA1 " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                       \
+    "v_add_u32 v121, v121, %[ngap]\n\t"                                                                                   \
+    "v_max3_i32 " GB ", v122, " GA ", " HIN "\n\t"                                                                        \
+    "v_add_u32_sdwa " TAN ", " GA ", sext(" SB ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BYTE "\n\t"
+#else
 #define S2(GA, GB, GA1, GB1, TAP, TAN, TBP, TBN, HIN, SA, SB, BYTE)                                                        \
     "v_add_u32 v121, v121, %[ngap]\n\t"                                                                                   \
     "v_max3_i32 v120, " TBP ", " GB1 ", v121\n\t"                                                                         \
@@ -30,6 +41,7 @@ __device__ __forceinline__ u64 now() { u64 t; asm volatile("s_memtime %0\n\ts_wa
     "v_max_i32_dpp " GA ", v120, " GA1 " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                                       \
     "v_max3_i32 " GB ", v122, " GA ", " HIN "\n\t"                                                                        \
     "v_add_u32_sdwa " TAN ", " GA ", sext(" SB ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" BYTE "\n\t"
+#endif
 #define EVEN(GA, GB, GA1, GB1, HIN, SA, SB, BYTE) S2(GA, GB, GA1, GB1, "v117", "v116", "v119", "v118", HIN, SA, SB, BYTE)
 #define ODD(GA, GB, GA1, GB1, HIN, SA, SB, BYTE) S2(GA, GB, GA1, GB1, "v116", "v117", "v118", "v119", HIN, SA, SB, BYTE)
 #define GRP0(SA, SB) EVEN("v64", "v80", "v79", "v95", "v100", SA, SB, "BYTE_0") ODD("v65", "v81", "v64", "v80", "v101", SA, SB, "BYTE_1")   \
@@ -129,6 +141,9 @@ __global__ void __launch_bounds__(64) perm2_k(Args a) {
         "v_mov_b32 v117, %[ta]\n\t"
         "v_mov_b32 v119, %[tb]\n\t"
         "v_mov_b32 v121, %[z0]\n\t"
+#ifdef LATE_Z
+        "v_add_u32 v121, v121, %[ngap]\n\t"
+#endif
         // lane 0 of every gA register is never written by the DPP op: give it the lane's constant once
         "v_mov_b32 v64, %[ga1]\n\tv_mov_b32 v65, %[ga1]\n\tv_mov_b32 v66, %[ga1]\n\tv_mov_b32 v67, %[ga1]\n\t"
         "v_mov_b32 v68, %[ga1]\n\tv_mov_b32 v69, %[ga1]\n\tv_mov_b32 v70, %[ga1]\n\tv_mov_b32 v71, %[ga1]\n\t"
