@@ -348,21 +348,22 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         // matrix of one pair, int32 H and P both stored, rows a multiple of 16; the alphabet (found on the device) must allow the
         // perm path -- so both kernels are enqueued and each checks for itself which of them has to work.  (debug bit 14: off)
         // Also: int8 P, either matrix left out, and band-resident launches (halo row in, last row out as granules).
-        const bool base_mode = j.d_H && j.d_P && j.p_elem_bytes == 4 && !j.d_top && !j.d_top_gran && !j.d_bot_gran;   // int32 H + P, whole matrix
+        const bool base_mode = j.d_H && j.d_P && j.h_elem_bytes == 4 && j.p_elem_bytes == 4 && !j.d_top && !j.d_top_gran && !j.d_bot_gran;   // int32 H + P, whole matrix
         // Where it pays: always for int32 H + P (8-byte stores of both matrices); in the other output formats while the strip chain
         // (~3.1 us per 63-column strip) rather than the output volume (~3.2 TB/s) bounds the fill -- measured: 262144 x 32768 with
         // int8 P +18 %, 131072^2 with int8 P -3 %, 262144^2 P-only -21 % (two byte stores per row and the in-block arg-max).
         const double est_chain = (double)S * 3.1e-6;
-        const double est_hbm = (double)(cols + 1) * (double)(rows + 1) * ((j.d_H ? 4.0 : 0.0) + (j.d_P ? (double)j.p_elem_bytes : 0.0)) / 3.2e12;
-        const bool pays = (j.d_H && j.d_P && j.p_elem_bytes == 4) || est_chain >= (j.d_H ? 0.5 : 2.0) * est_hbm || (c->opt_debug & 32768);
+        const double est_hbm = (double)(cols + 1) * (double)(rows + 1) * ((j.d_H ? (double)j.h_elem_bytes : 0.0) + (j.d_P ? (double)j.p_elem_bytes : 0.0)) / 3.2e12;
+        const bool pays = (j.d_H && j.d_P && j.p_elem_bytes == 4) || (j.d_H && j.h_elem_bytes == 8) || est_chain >= (j.d_H ? 0.5 : 2.0) * est_hbm || (c->opt_debug & 32768);
         const bool two_cols = pays && perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 &&
-                              j.h_elem_bytes == 4 && !j.d_left && !j.d_right && j.stride == cols + 1 && rows % 16 == 0 && rows >= 16 && cols >= 1 &&
+                              !j.d_left && !j.d_right && j.stride == cols + 1 && rows % 16 == 0 && rows >= 16 && cols >= 1 &&
                               (base_mode || (cols % 2 == 0)) &&   // (an odd column count leaves one lane with a single column: only the base mode handles it)
                               !(c->opt_debug & (2 | 8 | 64 | 128 | 512 | 16384));
         if (two_cols) {
             const int64_t S2 = (cols + 125) / 126;
             swk::FillParams p2 = p;
             p2.nstrips = (int)S2;
+            p2.h_bytes = j.h_elem_bytes;
             int per_cu = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, swk::sw_systolic2<6>, 768, 0));
             if (per_cu >= 1) {
@@ -371,10 +372,10 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 // the kernel; its P belongs to the band above)
                 const bool has_top = j.d_top || j.d_top_gran;
                 if (!has_top) {
-                    if (j.d_H) HIP_TRY(hipMemsetAsync(j.d_H, 0, (size_t)(cols + 1) * 4, stream));
+                    if (j.d_H) HIP_TRY(hipMemsetAsync(j.d_H, 0, (size_t)(cols + 1) * (size_t)j.h_elem_bytes, stream));
                     if (j.d_P) HIP_TRY(hipMemsetAsync(j.d_P, 0, (size_t)(cols + 1) * (size_t)j.p_elem_bytes, stream));
                 }
-                hipLaunchKernelGGL(swk::sw_zero_col0, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, stream, (int32_t*)j.d_H, j.d_P,
+                hipLaunchKernelGGL(swk::sw_zero_col0, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, stream, j.d_H, j.h_elem_bytes, j.d_P,
                                    j.p_elem_bytes, cols + 1, rows + 1, has_top ? 1 : 0);
                 const int nc2 = c->opt_consumers == 0 ? (chain_bound ? 5 : 6) : (int)std::min<int64_t>(7, c->opt_consumers);   // + 9 - nc2 importers
                 if (nc2 == 7) hipLaunchKernelGGL(swk::sw_systolic2<7>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);

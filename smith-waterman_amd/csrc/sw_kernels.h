@@ -52,6 +52,7 @@ struct FillParams {
     int64_t e4stride, edge4_pstride;
     unsigned int gbias;                  // 0 = perm path not eligible on the host side (score range)
     int skip_if_perm;                    // sw_systolic: leave when the perm path applies (sw_systolic2 was launched for that case)
+    int h_bytes;                         // sw_systolic2: bytes per H element (4 or 8); sw_systolic carries it as a template parameter
 };
 constexpr int SW_PERM_PAD = -100;        // score of any cell outside the sequences (perm producer)
 
@@ -62,7 +63,7 @@ __global__ void sw_systolic(const unsigned char* a, const unsigned char* b, cons
 __global__ void sw_wipe_u32(unsigned int* buf, size_t n);
 template <int NC>
 __global__ void sw_systolic2(const unsigned char* a, const unsigned char* b, FillParams p);
-__global__ void sw_zero_col0(int32_t* H, void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0);
+__global__ void sw_zero_col0(void* H, int h_bytes, void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0);
 __global__ void sw_alpha_scan(const unsigned char* a, int64_t cols, int64_t a_pstride, const unsigned char* b, int64_t rows, int64_t b_pstride,
                               int64_t npairs, unsigned int* present);
 __global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, int64_t b_pstride, unsigned char* bpad, unsigned short* bpad16,

@@ -1849,10 +1849,10 @@ __global__ void __launch_bounds__(256) sw_pad_b(const unsigned char* __restrict_
 
 // column 0 of the matrices the two-column kernel does not write itself (H int32, P int32 or int8; either may be NULL);
 // skip_row0: a band's row 0 is its halo row (H comes from the kernel, P belongs to the band above)
-__global__ void sw_zero_col0(int32_t* H, void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0) {
+__global__ void sw_zero_col0(void* H, int h_bytes, void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < rows1 && !(skip_row0 && r == 0)) {
-        if (H) H[r * M] = 0;
+        if (H) { if (h_bytes == 8) ((int64_t*)H)[r * M] = 0; else ((int32_t*)H)[r * M] = 0; }
         if (P) { if (p_bytes == 1) ((signed char*)P)[r * M] = 0; else ((int32_t*)P)[r * M] = 0; }
     }
 }

@@ -121,3 +121,28 @@ def test_lower_band_first_on_the_two_column_kernel(engine, oracle, swamd):
     from test_band_gpu import _bands
     ncu = engine.get_option("num_cus")
     _bands(engine, oracle, swamd, 5000, 2016, (1008,), reverse=True, max_blocks=max(8, ncu // 2 - 8))
+
+
+@pytest.mark.parametrize("p8", [False, True], ids=["p32", "p8"])
+@pytest.mark.parametrize("cols,rows", [(1000, 704), (2520, 320), (126, 16), (5000, 1296)])
+def test_int64_h(engine, oracle, cols, rows, p8):
+    """int64 H (BASELINE config 3's element type): {hA, 0, hB, 0} as one 16-byte store per lane and row."""
+    import torch
+    a, b = oracle.generate(cols, rows, 82)
+    H, P, mp = oracle.fill(a, b)
+    out = engine.fill(a, b, h_dtype=torch.int64, p_dtype=torch.int8 if p8 else None)
+    assert engine.get_option("last_strips2") == (cols + 125) // 126
+    assert out.H.dtype == torch.int64 and np.array_equal(out.H.cpu().numpy(), H.astype(np.int64))
+    assert np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
+    r = out.result()
+    assert r["max_pos"] == mp and r["max_score"] == int(H.flat[mp])
+    assert np.array_equal(engine.row_checksums(out.H), oracle.row_checksums(H))
+
+
+def test_int64_h_odd_columns_stay_on_the_one_column_kernel(engine, oracle):
+    import torch
+    a, b = oracle.generate(1007, 304, 83)
+    H, P, mp = oracle.fill(a, b)
+    out = engine.fill(a, b, h_dtype=torch.int64)
+    assert engine.get_option("last_strips2") == 0
+    assert np.array_equal(out.H.cpu().numpy(), H.astype(np.int64)) and np.array_equal(out.P.cpu().numpy(), P)
