@@ -25,6 +25,7 @@ step bench_old_producers 300 python bench.py --steps 10 --warmup 2 --no-cpu --de
 step bench_strip_scan 200 python bench.py --steps 5 --warmup 1 --no-cpu --engine 1 --placement-trials 1
 step bench_h64_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64
 step bench_h64_64k_first_alloc 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64 --placement-trials 1
+step bench_h64_64k_one_column 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64 --debug-flags 16384
 step bench_i32_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536
 step bench_i32_64k_first_alloc 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --placement-trials 1
 step bench_i32_64k_one_column 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --debug-flags 16384
