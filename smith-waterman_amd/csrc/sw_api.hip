@@ -708,7 +708,7 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
         if (rc != SW_OK) break;
         if (trial_ms) trial_ms[i] = k.ms;
         if (best < 0 || k.ms < cands[best].ms) best = (int)cands.size() - 1;
-        if (cands.size() >= 2) {   // clearly in the fast mode: stop looking
+        if ((int)cands.size() >= std::min(trials, 6)) {   // several placements seen (there are half-good ones) and clearly in the fast mode: stop looking
             float worst = 0.f;
             for (auto& x : cands) worst = std::max(worst, x.ms);
             if (cands[best].ms < 0.80f * worst) {   // (fast and slow mode are 20-25 % apart; the two-column kernel also has a half-good one in between)
