@@ -113,10 +113,13 @@ def chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows):
     return tau, lag
 
 
-def traffic_for(workload_key):
+def traffic_for(workload_key, kernel=None):
+    """HBM bytes per launch from the committed PMC passes (scripts/gpu_pmc.sh), if they were taken on the kernel that ran."""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-        return pm.get(workload_key, {}).get("traffic_bytes_per_launch")
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))).get(workload_key, {})
+        if kernel and pm.get("kernel") and pm["kernel"] != kernel:
+            return None
+        return pm.get("traffic_bytes_per_launch")
     except Exception:
         return None
 
@@ -194,7 +197,8 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
                    "placement_trials_ms": placement_ms, "value_first_allocation": value_first,
                    "ms_first_allocation": sum(ms_first) / len(ms_first)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_for(key),
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic_for(key, "sw_systolic2" if int(eng.get_option("last_strips2")) > 0 else "sw_systolic") if args.engine == 0 else None,
                      "kernel": ("sw_systolic2" if int(eng.get_option("last_strips2")) > 0 else "sw_systolic") if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
                      "algorithmic_bytes_per_cell": bytes_per_cell, "measured_contiguous_fill_GBs": fill_gbs,
                      "tau_step_ns": tau_ns, "strip_handoff_lag_ns": lag_ns,
