@@ -182,7 +182,8 @@ class BandPipeline:
 # =====================================================================================================
 class BandResident(BandPipeline):
     def __init__(self, dist, rank, world, engine, a, b, scores=(3, -3, -2), nchunks=64, p_dtype=None, want_h=True,
-                 reserve_cus=16, timeout_s=120.0):
+                 reserve_cus=16, timeout_s=120.0, placement=True):
+        """placement=False: plain allocations (the placement search fills with the whole GPU: not when ranks share one)."""
         import torch
         self.dist, self.rank, self.world, self.eng, self.scores = dist, rank, world, engine, scores
         self.a, self.b = np.asarray(a, np.uint8), np.asarray(b, np.uint8)
@@ -205,7 +206,7 @@ class BandResident(BandPipeline):
             self.d_a, _ = engine.to_device(self.a)
             self.d_b, _ = engine.to_device(self.b[self.lo:self.hi])
             self.placement_ms = []
-            if (world == 1 or self.nccl) and want_h:
+            if placement and (world == 1 or self.nccl) and want_h:
                 # where H and P lie in HBM moves the fill by 15-30 %: take them from the C-ABI allocator,
                 # which tries a few placements with fills of this band.  Its trial fills use the whole GPU, so not when
                 # several ranks may share one (gloo rehearsals).
