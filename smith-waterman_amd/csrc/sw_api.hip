@@ -61,6 +61,9 @@ struct sw_ctx {
     int64_t opt_consumers = 0;          // systolic: consumer waves per strip; 0 = by problem shape
     int64_t opt_waves_per_block = 4;
     int64_t opt_max_blocks = 0;         // 0 -> 2 * CUs
+    unsigned char* d_bcodes = nullptr; size_t bcodes_cap = 0;   // batch kernel: padded letter codes of every pair's b
+    int* d_bnd = nullptr; size_t bnd_cap = 0;                   // batch kernel: boundary columns between strips (ints)
+    int64_t last_batch_kernel = 0;      // 1: the last sw_batch_device call ran on sw_batch_wave (one pair per wave)
     int64_t last_grid = 0, last_strips = 0;
     int64_t last_strips2 = 0;           // strips of the two-column kernel in the last launch (0: not launched)
     std::map<void*, void*> out_base;    // sw_alloc_outputs: pointer handed out -> allocation to free
@@ -96,6 +99,8 @@ void sw_destroy(sw_ctx* c) {
     if (c->d_edge4) (void)hipFree(c->d_edge4);
     if (c->d_alpha) (void)hipFree(c->d_alpha);
     if (c->d_keys) (void)hipFree(c->d_keys);
+    if (c->d_bcodes) (void)hipFree(c->d_bcodes);
+    if (c->d_bnd) (void)hipFree(c->d_bnd);
     delete c;
 }
 
@@ -144,6 +149,7 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "last_grid")) return c->last_grid;
     if (!strcmp(name, "last_strips")) return c->last_strips;
     if (!strcmp(name, "last_strips2")) return c->last_strips2;
+    if (!strcmp(name, "last_batch_kernel")) return c->last_batch_kernel;
     return -1;
 }
 
@@ -501,6 +507,79 @@ int sw_fill_band_device(sw_ctx* c, const char* d_a, int64_t cols, const char* d_
     return fill_one(c, scores, j, cols, total_rows, d_result, stream_, "sw_fill_band_device");
 }
 
+// The batch kernel proper (csrc/sw_batch.hip): one pair per wave, no inter-workgroup traffic.  Returns 1 when the batch is not
+// eligible (the caller then runs it on the single-pair machinery): more than 8 distinct letters, scores that do not fit a signed
+// byte, or a pair whose matrix does not fit a 2 GiB buffer descriptor.
+static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t cols, const char* d_b, int64_t b_stride, int64_t rows,
+                                   int64_t npairs, const sw_scores* sc, int32_t* d_H, void* d_P, int p_elem_bytes, sw_result* d_results,
+                                   hipStream_t stream) {
+    if (sc->match > 127 || sc->match < -127 || sc->mismatch > 127 || sc->mismatch < -127) return 1;
+    if ((double)(rows + 132) * (double)(cols + 1) * 4.0 >= 2147483648.0) return 1;
+    const unsigned char* ua = (const unsigned char*)d_a;
+    const unsigned char* ub = (const unsigned char*)d_b;
+    // alphabet of the whole batch -> letter codes; the count decides whether the profile look-up applies
+    HIP_TRY(hipMemsetAsync(c->d_alpha, 0, 32, stream));
+    {
+        const int64_t total = (cols + rows) * npairs;
+        const unsigned nblk = (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 4095) / 4096, 2048));
+        hipLaunchKernelGGL(swk::sw_alpha_scan, dim3(nblk), dim3(256), 0, stream, ua, cols, a_stride, ub, rows, b_stride, npairs, (unsigned int*)c->d_alpha);
+    }
+    const int front = 64;
+    const int64_t per = ((rows + front + 80 + 15) / 16) * 16;
+    const int C = cols <= 256 ? 4 : cols <= 512 ? 8 : 16;
+    const int64_t nstrips = (cols + 64 * C - 1) / (64 * C);
+    const int64_t bnd_per = nstrips > 1 ? ((rows + 160 + 3) / 4) * 4 : 0;
+    // pairs per launch: bounds the workspace (codes: ~1.2 KB per 1024-row pair)
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(npairs, std::min<int64_t>((1ll << 30) / per, bnd_per ? (1ll << 30) / (bnd_per * 4) : npairs)));
+    if ((size_t)(chunk * per) > c->bcodes_cap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c->d_bcodes) HIP_TRY(hipFree(c->d_bcodes));
+        c->d_bcodes = nullptr; c->bcodes_cap = 0;
+        if (hipMalloc((void**)&c->d_bcodes, (size_t)(chunk * per) + 64) != hipSuccess) { set_err("workspace allocation failed"); return SW_ENOMEM; }
+        c->bcodes_cap = (size_t)(chunk * per);
+    }
+    if (bnd_per && (size_t)(chunk * bnd_per) > c->bnd_cap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c->d_bnd) HIP_TRY(hipFree(c->d_bnd));
+        c->d_bnd = nullptr; c->bnd_cap = 0;
+        if (hipMalloc((void**)&c->d_bnd, (size_t)(chunk * bnd_per) * 4) != hipSuccess) { set_err("workspace allocation failed"); return SW_ENOMEM; }
+        c->bnd_cap = (size_t)(chunk * bnd_per);
+        HIP_TRY(hipMemsetAsync(c->d_bnd, 0, c->bnd_cap * 4, stream));
+    }
+    const int64_t cells = (cols + 1) * (rows + 1);
+    for (int64_t k0 = 0; k0 < npairs; k0 += chunk) {
+        const int64_t n = std::min(chunk, npairs - k0);
+        hipLaunchKernelGGL(swk::sw_batch_codes, dim3((unsigned)std::min<int64_t>((per + 255) / 256, 64), (unsigned)n), dim3(256), 0, stream, ub + k0 * b_stride, rows,
+                           b_stride, c->d_bcodes, per, front, (const unsigned int*)c->d_alpha, c->d_alpha + 64);
+        if (k0 == 0) {   // the letter count (4 bytes) decides the path: the one host round trip of a batch call
+            unsigned int nletters = 0;
+            HIP_TRY(hipMemcpyAsync(&nletters, c->d_alpha + 64 + 256, 4, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (nletters > 8u) return 1;
+        }
+        swk::BatchParams bp;
+        memset(&bp, 0, sizeof bp);
+        bp.a = ua + k0 * a_stride; bp.a_pstride = a_stride; bp.cols = cols;
+        bp.bcode = c->d_bcodes; bp.bcode_pstride = per; bp.bfront = front;
+        bp.rows = rows; bp.npairs = n; bp.atab = c->d_alpha + 64;
+        bp.H = d_H ? d_H + k0 * cells : nullptr;
+        bp.P = d_P ? (void*)((char*)d_P + k0 * cells * p_elem_bytes) : nullptr;
+        bp.hp_pstride = cells;
+        bp.match = sc->match; bp.mismatch = sc->mismatch; bp.ngap = -sc->gap;
+        bp.bnd = c->d_bnd; bp.bnd_pstride = bnd_per;
+        bp.results = d_results + k0;
+        const int pb = d_P ? p_elem_bytes : 0;
+        const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+#define SB_LAUNCH(CC, PP) if (C == CC && pb == PP) hipLaunchKernelGGL((swk::sw_batch_wave<CC, PP>), grid, block, 0, stream, bp);
+        SB_LAUNCH(4, 0) SB_LAUNCH(4, 1) SB_LAUNCH(4, 4) SB_LAUNCH(8, 0) SB_LAUNCH(8, 1) SB_LAUNCH(8, 4) SB_LAUNCH(16, 0) SB_LAUNCH(16, 1) SB_LAUNCH(16, 4)
+#undef SB_LAUNCH
+        HIP_TRY(hipGetLastError());
+    }
+    c->last_batch_kernel = 1;
+    c->last_grid = (chunk + 3) / 4; c->last_strips = nstrips;
+    return SW_OK;
+}
+
 // BASELINE config 5: npairs independent cols x rows problems; pair k reads a at d_a + k*a_stride, b at d_b + k*b_stride.
 // d_H and/or d_P may be NULL (that matrix is not written); the arg-max is exact in every mode.
 int sw_batch_device_ex(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t cols, const char* d_b, int64_t b_stride, int64_t rows,
@@ -518,6 +597,11 @@ int sw_batch_device_ex(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t col
     HIP_TRY(hipSetDevice(c->device));
     DevOrder order(c, stream, false);
     if (order.rc) return order.rc;
+    c->last_batch_kernel = 0;
+    if (!(c->opt_debug & 65536)) {   // (debug bit 16: keep the batch on the single-pair machinery, A/B runs)
+        int rc = batch_one_pair_per_wave(c, d_a, a_stride, cols, d_b, b_stride, rows, npairs, sc, d_H, d_P, p_elem_bytes, d_results, stream);
+        if (rc != 1) return rc;      // 1: not eligible (alphabet of more than 8 letters, scores beyond a byte, huge pairs)
+    }
     const int64_t chunk_max = 4096;   // pairs per launch: bounds the edge / padded-b workspace
     if ((size_t)std::min(npairs, chunk_max) > c->keys_cap) {
         HIP_TRY(hipStreamSynchronize(stream));
@@ -557,13 +641,13 @@ int sw_batch_traceback_device(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t co
     }
     HIP_TRY(hipSetDevice(c->device));
     const int64_t cells = (cols + 1) * (rows + 1);
-    const dim3 grid((unsigned)((npairs + 63) / 64)), block(64);
+    const dim3 grid((unsigned)npairs), block(64);   // one wave per pair (csrc/sw_traceback.hip)
     if (p_elem_bytes == 4)
-        hipLaunchKernelGGL(swk::sw_traceback_batch<int32_t>, grid, block, 0, (hipStream_t)stream_, (int32_t*)d_P, cols + 1, cells, npairs, d_paths,
-                           d_paths ? path_cap : 0, d_results);
+        hipLaunchKernelGGL(swk::sw_traceback_wave<int32_t>, grid, block, 0, (hipStream_t)stream_, (int32_t*)d_P, cols + 1, rows + 1, cells, (int64_t)-1, d_paths,
+                           d_paths ? path_cap : 0, d_results, (int64_t*)nullptr);
     else
-        hipLaunchKernelGGL(swk::sw_traceback_batch<signed char>, grid, block, 0, (hipStream_t)stream_, (signed char*)d_P, cols + 1, cells, npairs,
-                           d_paths, d_paths ? path_cap : 0, d_results);
+        hipLaunchKernelGGL(swk::sw_traceback_wave<signed char>, grid, block, 0, (hipStream_t)stream_, (signed char*)d_P, cols + 1, rows + 1, cells, (int64_t)-1,
+                           d_paths, d_paths ? path_cap : 0, d_results, (int64_t*)nullptr);
     HIP_TRY(hipGetLastError());
     return SW_OK;
 }
@@ -618,6 +702,25 @@ int sw_align_auto(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t
     return rc;
 }
 
+static int traceback_launch(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path, int64_t path_cap,
+                            sw_result* d_result, int64_t* d_stop, hipStream_t stream) {
+    if (p_elem_bytes == 4)
+        hipLaunchKernelGGL(swk::sw_traceback_wave<int32_t>, dim3(1), dim3(64), 0, stream, (int32_t*)d_P, cols + 1, rows + 1, (int64_t)0, max_pos, d_path,
+                           d_path ? path_cap : 0, d_result, d_stop);
+    else
+        hipLaunchKernelGGL(swk::sw_traceback_wave<signed char>, dim3(1), dim3(64), 0, stream, (signed char*)d_P, cols + 1, rows + 1, (int64_t)0, max_pos, d_path,
+                           d_path ? path_cap : 0, d_result, d_stop);
+    HIP_TRY(hipGetLastError());
+    return SW_OK;
+}
+// (library-internal: the traceback that also reports where the walk stopped -- sw_multi_traceback hops bands with it)
+int sw_traceback_stop_device(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos, sw_result* d_result, int64_t* d_stop,
+                             void* stream_) {
+    if (!c || !d_P || !d_result || !d_stop || max_pos < 0 || max_pos >= (cols + 1) * (rows + 1)) { set_err("sw_traceback_stop_device: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    return traceback_launch(c, d_P, p_elem_bytes, cols, rows, max_pos, nullptr, 0, d_result, d_stop, (hipStream_t)stream_);
+}
+
 int sw_traceback_device_ex(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path,
                            int64_t path_cap, sw_result* d_result, void* stream_) {
     if (!c || !d_P || !d_result || cols < 0 || rows < 0 || max_pos < 0 || max_pos >= (cols + 1) * (rows + 1) ||
@@ -626,14 +729,7 @@ int sw_traceback_device_ex(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols,
         return SW_EINVAL;
     }
     HIP_TRY(hipSetDevice(c->device));
-    if (p_elem_bytes == 4)
-        hipLaunchKernelGGL(swk::sw_traceback<int32_t>, dim3(1), dim3(64), 0, (hipStream_t)stream_, (int32_t*)d_P, cols + 1, max_pos, d_path,
-                           d_path ? path_cap : 0, d_result);
-    else
-        hipLaunchKernelGGL(swk::sw_traceback<signed char>, dim3(1), dim3(64), 0, (hipStream_t)stream_, (signed char*)d_P, cols + 1, max_pos,
-                           d_path, d_path ? path_cap : 0, d_result);
-    HIP_TRY(hipGetLastError());
-    return SW_OK;
+    return traceback_launch(c, d_P, p_elem_bytes, cols, rows, max_pos, d_path, path_cap, d_result, nullptr, (hipStream_t)stream_);
 }
 int sw_traceback_device(sw_ctx* c, int32_t* d_P, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path,
                         int64_t path_cap, sw_result* d_result, void* stream_) {

@@ -1,0 +1,302 @@
+// sw_batch.hip -- BASELINE config 5: many independent pairs, ONE PAIR PER WAVE (gfx950).
+//
+// What is computed per pair is the reference recurrence, cell for cell (serial_smithW.c:187-256):
+//   H[i][j] = max(0, H[i-1][j-1] + s(i,j), H[i-1][j] + gap, H[i][j-1] + gap);  P = first of DIAGONAL, UP, LEFT that attains a
+//   positive maximum; maxPos = lowest linear index of max H.
+//
+// How.  A single pair is chain-bound (2N-1 dependent anti-diagonals); a batch is not, so nothing of the single-pair machinery
+// (producer / consumer waves, LDS rings, strips chained through HBM) is used here.  One 64-lane wave owns one pair.  Lane l keeps
+// the C adjacent columns  c0 = 64 C strip + C l + 1 .. c0 + C - 1  of the current row in registers and works, at step u, on row
+// r = u - l: the wave sweeps an anti-diagonal of 64 row segments down the matrix, the only cross-lane traffic being ONE DPP move
+// per step (lane l-1's last column = my left / diagonal neighbour).  Everything stays in H-space: the state of a lane is its row of
+// H, the floor is the inline constant 0, rows above the matrix are inert because cells outside the sequences score -1 (0 + -1 < 0).
+// Per cell: t = Hd + s (v_add_u32_sdwa, the score a byte of a v_perm_b32 profile look-up shared by 4 rows), u = max(Hu, Hl),
+// u -= -gap, H = max3(t, u, 0): 4.25 VALU; the arg-max adds 0.6 (row maximum by max3 tree, one compare against the wave's best
+// so far; the cell is looked for only in the rare steps that reach it), P 6 more (three compares, two selects, one SDWA select
+// that deposits the code byte in place).  Matrix rows leave as 16 (int8 P) or 64 (int32) contiguous bytes per lane.
+// Matrices wider than 64 C columns are swept strip after strip by the same wave; the boundary column goes through a scratch row.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sw_kernels.h"
+
+namespace swk {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+constexpr u32 SB_OOB = 0xFFFFFF00u;      // buffer offset beyond every descriptor: the store is dropped
+
+// Letter codes of every pair's b (rank of the byte value among the values present in the batch, 0..7) in a padded copy:
+// bcode[pair * per + front + i] = code(b[i]); 0x0D outside the sequence -- as a v_perm_b32 selector byte that yields 0xFF, the
+// score -1 of a cell outside the matrix.  Block (0,0) publishes the code table (atab[0..255], letter count at atab[256]).
+__global__ void __launch_bounds__(256) sw_batch_codes(const unsigned char* __restrict__ b, int64_t rows, int64_t b_pstride, unsigned char* __restrict__ bcode,
+                                                      int64_t per, int front, const unsigned int* __restrict__ present, unsigned char* __restrict__ atab) {
+    __shared__ unsigned char tab[256];
+    {
+        const int t = threadIdx.x;
+        int rank = 0, nletters = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const unsigned int m = present[w];
+            nletters += __popc(m);
+            if (w < (t >> 5)) rank += __popc(m);
+            else if (w == (t >> 5)) rank += __popc(m & ((1u << (t & 31)) - 1u));
+        }
+        const bool here = (present[t >> 5] >> (t & 31)) & 1u;
+        tab[t] = (here && nletters <= 8) ? (unsigned char)rank : (unsigned char)0x0D;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            atab[t] = tab[t];
+            if (t == 0) *(unsigned int*)(atab + 256) = (unsigned int)nletters;
+        }
+    }
+    __syncthreads();
+    const int64_t pair = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool in = (i >= front && i - front < rows);
+        bcode[pair * per + i] = in ? tab[b[pair * b_pstride + i - front]] : (unsigned char)0x0D;
+    }
+}
+
+__device__ __forceinline__ int sb_dpp_shr1(int old, int src) {   // lane l <- lane l-1; lane 0 keeps `old`
+    return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xF, 0xF, false);
+}
+__device__ __forceinline__ int sb_sbyte(u32 w, int j) { return (int)(signed char)(w >> (8 * j)); }
+
+__device__ __forceinline__ int sb_wave_max(int v) {   // max over the 64 lanes, wave-uniform result (v >= 0)
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true));   // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true));   // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true));   // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true));   // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true));   // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true));   // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// P code of a cell, deposited as byte BYTE of the packed register `acc` in ONE select: acc.byte = (h == 0) ? 0 : p
+template <int BYTE>
+__device__ __forceinline__ void sb_deposit(u32& acc, int p, int h, int zero) {
+    if constexpr (BYTE == 0)
+        asm("v_cmp_eq_u32 vcc, 0, %2\n\tv_cndmask_b32_sdwa %0, %1, %3, vcc dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+            : "+v"(acc) : "v"(p), "v"(h), "v"(zero) : "vcc");
+    else if constexpr (BYTE == 1)
+        asm("v_cmp_eq_u32 vcc, 0, %2\n\tv_cndmask_b32_sdwa %0, %1, %3, vcc dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+            : "+v"(acc) : "v"(p), "v"(h), "v"(zero) : "vcc");
+    else if constexpr (BYTE == 2)
+        asm("v_cmp_eq_u32 vcc, 0, %2\n\tv_cndmask_b32_sdwa %0, %1, %3, vcc dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+            : "+v"(acc) : "v"(p), "v"(h), "v"(zero) : "vcc");
+    else
+        asm("v_cmp_eq_u32 vcc, 0, %2\n\tv_cndmask_b32_sdwa %0, %1, %3, vcc dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+            : "+v"(acc) : "v"(p), "v"(h), "v"(zero) : "vcc");
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void sb_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sb_for<I + 1, N>(f);
+    }
+}
+
+typedef int sb_v4i __attribute__((ext_vector_type(4)));
+typedef int sb_v2i __attribute__((ext_vector_type(2)));
+
+// C: columns per lane (4, 8, 16); PB: bytes per P element written (0: P not written, 1: int8, 4: int32)
+template <int C, int PB>
+__global__ void __launch_bounds__(256) sw_batch_wave(BatchParams p) {
+    static_assert(C % 4 == 0 && C <= 16, "C is a multiple of 4 (packed P bytes, 16-byte stores)");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (pair >= p.npairs) return;
+    if (*(const unsigned int*)(p.atab + 256) > 8u) return;   // (the host has already checked: kept as a guard)
+    const int cols = (int)p.cols, rows = (int)p.rows, M = cols + 1;
+    const int ngap = p.ngap;
+    const unsigned char* __restrict__ a = p.a + pair * p.a_pstride;
+    const unsigned char* __restrict__ bcl = p.bcode + pair * p.bcode_pstride + p.bfront - 1 - lane;   // bcl[u] = code of b[u - lane - 1]
+    const bool wh = p.H != nullptr;
+    constexpr bool wp = PB != 0;
+    const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)(p.H ? p.H + pair * p.hp_pstride : nullptr), 0,
+                                                                        wh ? (int)((int64_t)(rows + 1) * M * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.P ? (char*)p.P + pair * p.hp_pstride * (PB ? PB : 1) : nullptr), 0,
+                                                                        wp ? (int)((int64_t)(rows + 1) * M * PB) : 0, 0x00020000);
+    const int nstrips = (cols + 64 * C - 1) / (64 * C);
+    const bool multi = nstrips > 1;
+    // boundary column between strips: bnd[r + 64] = H[r][last column of the strip], rows -63 .. rows (+ slack)
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)(multi ? p.bnd + pair * p.bnd_pstride : nullptr), 0,
+                                                                        multi ? (int)(p.bnd_pstride * 4) : 0, 0x00020000);
+    const bool ragged = (cols % C) != 0;
+    const u32 mis4 = 0x01010101u * (u32)(unsigned char)(signed char)p.mismatch;
+    const u32 dmm = ((u32)(unsigned char)(signed char)p.match) ^ ((u32)(unsigned char)(signed char)p.mismatch);
+    u64 kbest = 0;         // per lane: best (score << 40 | MASK - index) over the strips done
+    int sbest = 1;         // wave-uniform: highest valid H seen so far (at least 1: zeros never count)
+    const int G = (rows + 64 + 3) / 4;
+
+    for (int st = 0; st < nstrips; ++st) {
+        const int c0 = st * 64 * C + lane * C + 1;
+        const int nval = min(C, max(0, cols - c0 + 1));            // columns of this lane inside the matrix
+        // score profiles of my columns: byte L = score against letter code L (lo: codes 0..3, hi: 4..7)
+        u32 lo[C], hi[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int c = c0 + k;
+            if (c <= cols) {
+                const u32 code = p.atab[a[c - 1]];
+                lo[k] = mis4 ^ (code < 4u ? dmm << (8 * code) : 0u);
+                hi[k] = mis4 ^ (code >= 4u && code < 8u ? dmm << (8 * (code - 4u)) : 0u);
+            } else {
+                lo[k] = hi[k] = 0xFFFFFFFFu;                         // outside the matrix: -1 against everything
+            }
+        }
+        int h[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) h[k] = 0;
+        int diag0 = 0, lbest = 0, lidx = 0;
+        // output offsets of my row segment at step u = 0 (row -lane): wraps to a huge unsigned offset above the matrix, runs past
+        // the descriptor below it -- stores outside rows 0..rows are dropped by the bounds check.  (Row 0 is stored too: H = P = 0.)
+        const bool full = nval == C;
+        u32 voffH = (full && wh) ? (u32)((-lane * M + c0) * 4) : SB_OOB;
+        u32 voffP = (full && wp) ? (u32)((-lane * M + c0) * PB) : SB_OOB;
+        const bool col0 = st == 0 && lane == 0;
+        u32 voffH0 = (wh && col0) ? 0u : SB_OOB, voffP0 = (wp && col0) ? 0u : SB_OOB;   // column 0
+        // (lanes that do not store keep their out-of-range offset: pitch 0)
+        const u32 pitchH = full ? (u32)(M * 4) : 0u, pitchP = full ? (u32)(M * PB) : 0u;
+        const u32 pitchH0 = col0 ? (u32)(M * 4) : 0u, pitchP0 = col0 ? (u32)(M * PB) : 0u;
+        // boundary column: lane 63 writes its last column (row u - 63) for the next strip, lane 0 reads row u of the previous one
+        const bool bw = multi && st + 1 < nstrips, br = multi && st > 0;
+        // (sc1 loads: served from L2, which this wave's own earlier stores have reached once vmcnt has drained)
+        sb_v4i bq = {0, 0, 0, 0};
+        const u32 voffB = lane == 0 ? 64u * 4u : SB_OOB;
+        if (br) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bq = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)voffB, 0, 16);
+        }
+        u32 selw_next;
+        __builtin_memcpy(&selw_next, bcl, 4);
+
+        for (int g = 0; g < G; ++g) {
+            const u32 selw = selw_next;
+            __builtin_memcpy(&selw_next, bcl + 4 * (g + 1), 4);     // codes of the next 4 rows (the padded copy covers the overrun)
+            u32 S[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) S[k] = __builtin_amdgcn_perm(hi[k], lo[k], selw);
+            const sb_v4i bcur = bq;
+            if (br) bq = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)voffB, 16 * (g + 1), 16);
+
+            sb_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const int u = 4 * g + j;
+                const int left = sb_dpp_shr1(br ? bcur[j] : 0, h[C - 1]);
+                int dprev = diag0, prev = left;
+                diag0 = left;
+                u32 pk[C / 4];
+                int p32[C];
+#pragma unroll
+                for (int q = 0; q < C / 4; ++q) pk[q] = 0;
+                sb_for<0, C>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    const int old = h[k];
+                    const int t = dprev + sb_sbyte(S[k], j);
+                    const int u2 = max(old, prev);
+                    const int hn = max(max(t, u2 - ngap), 0);
+                    if constexpr (PB != 0) {
+                        int pc = (old == u2) ? SW_UP : SW_LEFT;
+                        pc = (t == hn) ? SW_DIAGONAL : pc;
+                        if constexpr (PB == 1) sb_deposit<k & 3>(pk[k >> 2], pc, hn, 0);
+                        else p32[k] = (hn == 0) ? SW_NONE : pc;
+                    }
+                    h[k] = hn;
+                    dprev = old;
+                    prev = hn;
+                });
+                // ---- stores: my row segment of H and P (dropped outside rows 0..rows), column 0 by lane 0
+                if (wh) {
+#pragma unroll
+                    for (int q = 0; q < C / 4; ++q) {
+                        const sb_v4i v = {h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rH, (int)voffH, 16 * q, 0);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(0, rH, (int)voffH0, 0, 0);
+                    if (ragged) {
+#pragma unroll
+                        for (int k = 0; k < C - 1; ++k)
+                            if (!full && k < nval) __builtin_amdgcn_raw_buffer_store_b32(h[k], rH, (int)((u32)((u - lane) * M + c0 + k) * 4u), 0, 0);
+                    }
+                    voffH += pitchH; voffH0 += pitchH0;
+                }
+                if constexpr (PB == 4) {
+#pragma unroll
+                    for (int q = 0; q < C / 4; ++q) {
+                        const sb_v4i v = {p32[4 * q], p32[4 * q + 1], p32[4 * q + 2], p32[4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rP, (int)voffP, 16 * q, 0);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(0, rP, (int)voffP0, 0, 0);
+                    if (ragged) {
+#pragma unroll
+                        for (int k = 0; k < C - 1; ++k)
+                            if (!full && k < nval) __builtin_amdgcn_raw_buffer_store_b32(p32[k], rP, (int)((u32)((u - lane) * M + c0 + k) * 4u), 0, 0);
+                    }
+                    voffP += pitchP; voffP0 += pitchP0;
+                } else if constexpr (PB == 1) {
+                    if constexpr (C == 16) {
+                        const sb_v4i v = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rP, (int)voffP, 0, 0);
+                    } else if constexpr (C == 8) {
+                        const sb_v2i v = {(int)pk[0], (int)pk[1]};
+                        __builtin_amdgcn_raw_buffer_store_b64(v, rP, (int)voffP, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32((int)pk[0], rP, (int)voffP, 0, 0);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)0, rP, (int)voffP0, 0, 0);
+                    if (ragged) {
+#pragma unroll
+                        for (int k = 0; k < C - 1; ++k)
+                            if (!full && k < nval)
+                                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(pk[k >> 2] >> (8 * (k & 3))), rP, (int)((u32)((u - lane) * M + c0 + k)), 0, 0);
+                    }
+                    voffP += pitchP; voffP0 += pitchP0;
+                }
+                if (bw) __builtin_amdgcn_raw_buffer_store_b32(h[C - 1], rB, lane == 63 ? 4 : (int)SB_OOB, 4 * u, 0);   // row u - 63 at index row + 64
+                // ---- arg-max: the row maximum against the wave's best; the cell is looked for only when it may matter
+                int m = h[0];
+#pragma unroll
+                for (int k = 1; k + 1 < C; k += 2) m = max(max(m, h[k]), h[k + 1]);
+                m = max(m, h[C - 1]);
+                if (__builtin_amdgcn_ballot_w64(m >= sbest) != 0) {
+                    const int r = u - lane;
+                    const bool rv = r >= 1 && r <= rows;
+                    int mv = 0;
+#pragma unroll
+                    for (int k = 0; k < C; ++k) {
+                        const int v = (rv && k < nval) ? h[k] : 0;
+                        if (v > lbest) { lbest = v; lidx = r * M + c0 + k; }
+                        mv = max(mv, v);
+                    }
+                    sbest = max(sbest, sb_wave_max(mv));
+                }
+            });
+        }
+        if (lbest > 0) {
+            const u64 key = ((u64)(u32)lbest << 40) | (SW_KEY_IDX_MASK - (u64)(u32)lidx);
+            kbest = key > kbest ? key : kbest;
+        }
+    }
+    // the pair's arg-max: highest score, lowest linear index among equals (serial_smithW.c:240-242)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u32 olo = (u32)__shfl_xor((int)(u32)kbest, off), ohi = (u32)__shfl_xor((int)(u32)(kbest >> 32), off);
+        const u64 o = ((u64)ohi << 32) | olo;
+        kbest = o > kbest ? o : kbest;
+    }
+    if (lane == 0) {
+        sw_result* res = p.results + pair;
+        res->max_score = (int64_t)(kbest >> 40);
+        res->max_pos = kbest ? (int64_t)(SW_KEY_IDX_MASK - (kbest & SW_KEY_IDX_MASK)) : 0;
+        res->path_len = 0;
+    }
+}
+
+#define SB_INST(C, PB) template __global__ void sw_batch_wave<C, PB>(BatchParams);
+SB_INST(4, 0) SB_INST(4, 1) SB_INST(4, 4) SB_INST(8, 0) SB_INST(8, 1) SB_INST(8, 4) SB_INST(16, 0) SB_INST(16, 1) SB_INST(16, 4)
+#undef SB_INST
+
+}  // namespace swk

@@ -56,6 +56,23 @@ struct FillParams {
 };
 constexpr int SW_PERM_PAD = -100;        // score of any cell outside the sequences (perm producer)
 
+// sw_batch.hip: one pair per wave (BASELINE config 5)
+struct BatchParams {
+    const unsigned char* a; int64_t a_pstride, cols;
+    const unsigned char* bcode; int64_t bcode_pstride; int bfront;   // padded letter codes of b (sw_batch_codes)
+    int64_t rows, npairs;
+    const unsigned char* atab;       // letter code of every byte value; [256..259] = number of letters
+    int32_t* H; void* P;             // either may be NULL; pair k at element offset k * hp_pstride
+    int64_t hp_pstride;
+    int match, mismatch, ngap;       // plain scores (H-space), ngap = -gap
+    int* bnd; int64_t bnd_pstride;   // boundary column between strips (only when cols > 64 * C), ints per pair
+    sw_result* results;
+};
+__global__ void sw_batch_codes(const unsigned char* b, int64_t rows, int64_t b_pstride, unsigned char* bcode, int64_t per, int front,
+                               const unsigned int* present, unsigned char* atab);
+template <int C, int PB>
+__global__ void sw_batch_wave(BatchParams p);
+
 template <typename HT, int B>
 __global__ void sw_strip_scan(const unsigned char* a, const unsigned char* b, FillParams p);
 template <typename HT, int NS, int NC>
@@ -70,9 +87,8 @@ __global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, in
                          unsigned char* bcode, const unsigned int* present, unsigned char* atab, int64_t per);
 __global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res, int n);
 template <typename PT>
-__global__ void sw_traceback(PT* P, int64_t M, int64_t maxPos, int64_t* path, int64_t cap, sw_result* res);
-template <typename PT>
-__global__ void sw_traceback_batch(PT* P, int64_t M, int64_t pstride, int64_t npairs, int64_t* paths, int64_t cap, sw_result* res);
+__global__ void sw_traceback_wave(PT* P, int64_t M, int64_t rows1, int64_t pstride, int64_t start_pos, int64_t* paths, int64_t cap, sw_result* res,
+                                  int64_t* stop);
 template <typename T> __global__ void sw_row_checksums(const T* X, int64_t m, unsigned long long* cs);
 __global__ void sw_widen_p8(const signed char* P8, int32_t* P32, size_t n);
 

@@ -271,45 +271,6 @@ __global__ void sw_finalize(const unsigned long long* key, const unsigned int* a
     res[i].path_len = *abort_flag ? -1 : 0;
 }
 
-// backtrack(), serial_smithW.c:262-277: one lane walks P from maxPos and negates the path.
-template <typename PT>
-__global__ void sw_traceback(PT* __restrict__ P, int64_t M, int64_t maxPos, int64_t* __restrict__ path,
-                             int64_t cap, sw_result* res) {
-    if (threadIdx.x | blockIdx.x) return;
-    int64_t len = 0, pos = maxPos;
-    int pr = P[pos];
-    while (pr > 0) {
-        const int64_t pred = (pr == 3) ? pos - M - 1 : (pr == 1) ? pos - M : pos - 1;
-        P[pos] = (PT)-pr;
-        if (path && len < cap) path[len] = pos;
-        ++len;
-        pos = pred;
-        pr = P[pos];
-    }
-    res->path_len = len;
-}
-
-// backtrack() for a batch of independent problems (BASELINE config 5): one lane per pair walks that pair's P from
-// res[k].max_pos (pair-local index), negates the path, optionally records it, and sets res[k].path_len.
-template <typename PT>
-__global__ void sw_traceback_batch(PT* __restrict__ P, int64_t M, int64_t pstride, int64_t npairs, int64_t* __restrict__ paths,
-                                   int64_t cap, sw_result* __restrict__ res) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= npairs || res[k].path_len < 0) return;
-    PT* Pk = P + k * pstride;
-    int64_t* path = paths ? paths + k * cap : nullptr;
-    int64_t len = 0, pos = res[k].max_pos;
-    int pr = Pk[pos];
-    while (pr > 0) {
-        const int64_t pred = (pr == 3) ? pos - M - 1 : (pr == 1) ? pos - M : pos - 1;
-        Pk[pos] = (PT)-pr;
-        if (path && len < cap) path[len] = pos;
-        ++len;
-        pos = pred;
-        pr = Pk[pos];
-    }
-    res[k].path_len = len;
-}
 // compact predecessor matrix -> the reference's int32 layout (same codes, sign-extended): 16 codes per thread and pass
 __global__ void sw_widen_p8(const signed char* __restrict__ P8, int32_t* __restrict__ P32, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x * 16;
@@ -325,8 +286,6 @@ __global__ void sw_widen_p8(const signed char* __restrict__ P8, int32_t* __restr
         }
     }
 }
-template __global__ void sw_traceback_batch<int32_t>(int32_t*, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*);
-template __global__ void sw_traceback_batch<signed char>(signed char*, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*);
 
 // cs[i] = sum_j (u64)(u32)X[i][j] * ((j+1) * 0x9E3779B97F4A7C15); one block per row
 template <typename T>
@@ -356,7 +315,5 @@ __global__ void __launch_bounds__(256) sw_row_checksums(const T* __restrict__ X,
 template __global__ void sw_row_checksums<int32_t>(const int32_t*, int64_t, u64*);
 template __global__ void sw_row_checksums<int64_t>(const int64_t*, int64_t, u64*);
 template __global__ void sw_row_checksums<signed char>(const signed char*, int64_t, u64*);
-template __global__ void sw_traceback<int32_t>(int32_t*, int64_t, int64_t, int64_t*, int64_t, sw_result*);
-template __global__ void sw_traceback<signed char>(signed char*, int64_t, int64_t, int64_t*, int64_t, sw_result*);
 
 }  // namespace swk

@@ -40,6 +40,7 @@ struct sw_multi_band {
     bool placed = false;               // d_H / d_P come from sw_alloc_outputs (a band with a GPU of its own)
     uint32_t* h_done = nullptr;        // host-pinned, one flag per strip
     sw_result* d_res = nullptr;
+    int64_t* d_stop = nullptr;         // where this band's part of a traceback stopped (sw_multi_traceback)
     hipStream_t stream = nullptr, copy = nullptr;
     sw_result res = {0, 0, 0};
 };
@@ -56,6 +57,9 @@ struct sw_multi {
 
 extern "C" {
 
+int sw_traceback_stop_device(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos, sw_result* d_result, int64_t* d_stop,
+                             void* stream);   // sw_api.hip (library-internal)
+
 void sw_multi_free(sw_multi* m) {
     if (!m) return;
     for (auto& b : m->bands) {
@@ -67,7 +71,7 @@ void sw_multi_free(sw_multi* m) {
         else { (void)hipFree(b.d_H); (void)hipFree(b.d_P); }
         if (b.host_gran) { if (b.d_top) (void)hipHostFree(b.d_top); if (b.d_bot) (void)hipHostFree(b.d_bot); }
         else { (void)hipFree(b.d_top); (void)hipFree(b.d_bot); }
-        (void)hipFree(b.d_res);
+        (void)hipFree(b.d_res); (void)hipFree(b.d_stop);
         if (b.h_done) (void)hipHostFree(b.h_done);
         if (b.ctx) sw_destroy(b.ctx);
     }
@@ -129,7 +133,7 @@ int sw_multi_create(const int* devices, int ndev, const char* a, int64_t cols, c
         } else {
             ok = ok && (!want_h || dev_alloc(&bd.d_H, cells * 4)) && dev_alloc(&bd.d_P, cells * (size_t)p_elem_bytes);
         }
-        ok = ok && dev_alloc((void**)&bd.d_res, sizeof(sw_result)) && (g == 0 || gran_alloc(&bd.d_top)) && (g == nb - 1 || gran_alloc(&bd.d_bot));
+        ok = ok && dev_alloc((void**)&bd.d_res, sizeof(sw_result)) && dev_alloc((void**)&bd.d_stop, 8) && (g == 0 || gran_alloc(&bd.d_top)) && (g == nb - 1 || gran_alloc(&bd.d_bot));
         if (!ok) { (void)hipGetLastError(); set_err("sw_multi_create: band %d does not fit device %d", g, bd.device); rc = SW_ENOMEM; break; }
         if (g < nb - 1 && hipHostMalloc((void**)&bd.h_done, (size_t)S * 4, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {
             set_err("sw_multi_create: pinned allocation failed"); rc = SW_ENOMEM; break;
@@ -179,12 +183,24 @@ int sw_multi_fill(sw_multi* m, const sw_scores* scores, int nchunks, sw_result* 
         for (int k = 0; k < nb; ++k) share += (m->bands[k].device == bd.device);
         const int rc = sw_fill_band_device(bd.ctx, bd.d_a, cols, bd.d_b, bd.hi - bd.lo, m->rows, scores, bd.d_H, 4, bd.d_P, m->p_elem_bytes,
                                            bd.d_top, bd.d_top ? tag : 0, bd.d_bot, bd.d_bot ? tag : 0, bd.h_done, 0, share > 1, bd.d_res, bd.stream);
-        if (rc != SW_OK) return rc;
+        if (rc != SW_OK) {   // bands already launched would wait for a halo that never comes: they give up after "band_wait_ms"
+            for (int k = 0; k < g; ++k) { (void)hipSetDevice(m->bands[k].device); (void)hipStreamSynchronize(m->bands[k].stream); }
+            return rc;
+        }
     }
-    // relay: chunk k of band g's last row goes to band g+1 as soon as all its strips have raised their flag
+    // relay: chunk k of band g's last row goes to band g+1 as soon as all its strips have raised their flag.  A granule
+    // {tag, H} is valid only as a whole, so (a) chunks are cut at EVEN granule indices -- every piece starts and ends on a
+    // 16-byte boundary and no transport has a reason to move a granule in two parts -- and (b) the host-memory path (bands
+    // that share a GPU) copies granule by granule with 8-byte atomic stores instead of memcpy.
     std::vector<int64_t> next(nb, 0);   // next strip to forward per band
     bool busy = nb > 1;
-    const auto deadline = t0 + std::chrono::seconds(120);
+    auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);   // patience WITHOUT progress
+    auto give_up = [&](int rc) {
+        // leave no band kernel in flight: raise every context's abort flag is not reachable from here, but a band that
+        // never gets its halo gives up by itself after "band_wait_ms"; wait for all of them before returning
+        for (auto& bd : m->bands) { (void)hipSetDevice(bd.device); (void)hipStreamSynchronize(bd.copy); (void)hipStreamSynchronize(bd.stream); }
+        return rc;
+    };
     while (busy) {
         busy = false;
         bool moved = false;
@@ -196,19 +212,27 @@ int sw_multi_fill(sw_multi* m, const sw_scores* scores, int nchunks, sw_result* 
                 bool ready = true;
                 for (int64_t s = s0; s < s1 && ready; ++s) ready = (__atomic_load_n(&src.h_done[s], __ATOMIC_ACQUIRE) == tag);
                 if (!ready) break;
-                const int64_t c0 = (s0 == 0) ? 0 : 63 * s0 + 1, c1 = std::min<int64_t>(cols, 63 * s1) + 1;
+                // strips s0 .. s1-1 cover columns 63 s0 + 1 .. 63 s1; cut at even indices: a chunk starts at the even index at or
+                // below its first column (that granule belongs to a finished strip) and ends below the even index at or
+                // below the next chunk's first column (the last chunk ends at cols + 1)
+                const int64_t c0 = (s0 == 0) ? 0 : ((63 * s0 + 1) & ~1ll);
+                const int64_t c1 = (s1 >= S) ? cols + 1 : ((63 * s1 + 1) & ~1ll);
                 HIP_TRYM(hipSetDevice(dst.device));
                 if (src.host_gran && dst.host_gran) {
-                    memcpy(dst.d_top + c0, src.d_bot + c0, (size_t)(c1 - c0) * 8);   // both in host-pinned memory
+                    for (int64_t c = c0; c < c1; ++c)
+                        __atomic_store_n(dst.d_top + c, __atomic_load_n(src.d_bot + c, __ATOMIC_RELAXED), __ATOMIC_RELAXED);   // both in host-pinned memory
                     __atomic_thread_fence(__ATOMIC_RELEASE);
-                } else
-                    HIP_TRYM(hipMemcpyPeerAsync(dst.d_top + c0, dst.device, src.d_bot + c0, src.device, (size_t)(c1 - c0) * 8, dst.copy));
+                } else if (c1 > c0) {
+                    const hipError_t e = hipMemcpyPeerAsync(dst.d_top + c0, dst.device, src.d_bot + c0, src.device, (size_t)(c1 - c0) * 8, dst.copy);
+                    if (e != hipSuccess) { set_err("sw_multi_fill: peer copy failed: %s", hipGetErrorString(e)); return give_up(SW_EDEVICE); }
+                }
                 next[g] = s1;
                 moved = true;
             }
             if (next[g] < S) busy = true;
         }
-        if (busy && !moved && std::chrono::steady_clock::now() > deadline) { set_err("sw_multi_fill: the band pipeline stalled"); return SW_ETIMEOUT; }
+        if (moved) deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+        else if (busy && std::chrono::steady_clock::now() > deadline) { set_err("sw_multi_fill: the band pipeline stalled"); return give_up(SW_ETIMEOUT); }
     }
     if (getenv("SW_MULTI_DEBUG")) {
         fprintf(stderr, "sw_multi_fill: relay done after %.3f s;", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -248,28 +272,20 @@ int sw_multi_traceback(sw_multi* m, int64_t* path_len) {
         sw_multi_band& bd = m->bands[g];
         if (!(bd.lo < row && row <= bd.hi)) continue;
         HIP_TRYM(hipSetDevice(bd.device));
-        const int64_t cap = (bd.hi - bd.lo) + m->cols + 2;
-        int64_t* d_path = nullptr;
-        HIP_TRYM(hipMalloc((void**)&d_path, (size_t)cap * 8));
-        int rc = sw_traceback_device_ex(bd.ctx, bd.d_P, m->p_elem_bytes, m->cols, bd.hi - bd.lo, (row - bd.lo) * M + col, d_path, cap, bd.d_res, bd.stream);
-        sw_result r = {0, 0, 0};
-        int64_t last = -1;
-        if (rc == SW_OK && hipStreamSynchronize(bd.stream) == hipSuccess && hipMemcpy(&r, bd.d_res, sizeof r, hipMemcpyDeviceToHost) == hipSuccess &&
-            r.path_len > 0)
-            (void)hipMemcpy(&last, d_path + (r.path_len - 1), 8, hipMemcpyDeviceToHost);
-        (void)hipFree(d_path);
+        // the band's walk stops at the first cell with P <= 0: inside the band (the end of the path) or in the band's row 0,
+        // which belongs to the band above (its P is kept NONE here) -- then that band takes over at its last row
+        int rc = sw_traceback_stop_device(bd.ctx, bd.d_P, m->p_elem_bytes, m->cols, bd.hi - bd.lo, (row - bd.lo) * M + col, bd.d_res, bd.d_stop, bd.stream);
         if (rc != SW_OK) return rc;
+        sw_result r = {0, 0, 0};
+        int64_t stop = 0;
+        HIP_TRYM(hipStreamSynchronize(bd.stream));
+        HIP_TRYM(hipMemcpy(&r, bd.d_res, sizeof r, hipMemcpyDeviceToHost));
+        HIP_TRYM(hipMemcpy(&stop, bd.d_stop, 8, hipMemcpyDeviceToHost));
         walking = false;
         if (r.path_len > 0) {
             total += r.path_len;
-            // where the last negated cell points
-            int32_t code4 = 0; signed char code1 = 0;
-            if (m->p_elem_bytes == 4) HIP_TRYM(hipMemcpy(&code4, (int32_t*)bd.d_P + last, 4, hipMemcpyDeviceToHost));
-            else { HIP_TRYM(hipMemcpy(&code1, (signed char*)bd.d_P + last, 1, hipMemcpyDeviceToHost)); code4 = code1; }
-            const int pr = -code4;
-            const int64_t nxt = (pr == SW_DIAGONAL) ? last - M - 1 : (pr == SW_UP) ? last - M : last - 1;
-            const int64_t r2 = nxt / M, c2 = nxt % M;
-            if (r2 == 0 && bd.lo > 0) { row = bd.lo; col = c2; walking = true; }   // crossed into the band above
+            const int64_t r2 = stop / M, c2 = stop % M;
+            if (r2 == 0 && bd.lo > 0 && c2 > 0) { row = bd.lo; col = c2; walking = true; }   // crossed into the band above
         }
     }
     m->result.path_len = total;

@@ -1,0 +1,158 @@
+// sw_traceback.hip -- backtrack(), serial_smithW.c:262-277, wave-cooperative: ONE WAVE per problem (gfx950).
+//   do { pred = P[pos] == DIAGONAL ? pos-m-1 : P[pos] == UP ? pos-m : pos-1;  P[pos] *= -1;  pos = pred; } while (P[pos] != NONE)
+// A single lane chasing P through HBM pays a full memory latency per step (441 ns measured in round 2).  Here the wave loads a
+// 64-row x 64-column window of P whose bottom-right part holds the cursor -- 64 coalesced row loads in flight at once, row q in
+// the literal register v[64+q], column = lane -- and walks it without touching memory: the cursor (ti, tj) lives in SGPRs, a step
+// is one VGPR-indexed v_mov_b32 (row ti) + v_readlane_b32 (lane tj) + a handful of SALU ops, and the codes of up to 64 steps are collected in
+// one VGPR (v_writelane_b32, lane = step).  A flush turns them into positions with one wave prefix sum and negates the cells /
+// writes the path with ONE 64-lane store each.  The walk only moves up and left, so it leaves a window through its top or left
+// edge, and the next window is anchored at the new cursor.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sw_kernels.h"
+
+namespace swk {
+
+typedef unsigned int u32;
+
+#define TB_WINDOW_REGS                                                                                                       \
+    "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", \
+    "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104",   \
+    "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122",   \
+    "v123", "v124", "v125", "v126", "v127"
+
+// rows q = 0..63 of the window into v[64+q]; bytes beyond the matrix read as 0 (buffer bounds check)
+template <typename PT>
+__device__ __forceinline__ void tb_load_window(const PT* base, u32 num_records, u32 row_pitch_bytes, int lane) {
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    const int d0 = __builtin_amdgcn_readfirstlane((int)(u32)b), d1 = __builtin_amdgcn_readfirstlane((int)(u32)(b >> 32));
+    const u32 voff = (u32)lane * (u32)sizeof(PT);
+#define TB_LD4(LD, R0, R1, R2, R3)                                                                                          \
+    LD " v" #R0 ", %[vo], s[76:79], s75 offen\n\ts_add_u32 s75, s75, %[pitch]\n\t"                                          \
+    LD " v" #R1 ", %[vo], s[76:79], s75 offen\n\ts_add_u32 s75, s75, %[pitch]\n\t"                                          \
+    LD " v" #R2 ", %[vo], s[76:79], s75 offen\n\ts_add_u32 s75, s75, %[pitch]\n\t"                                          \
+    LD " v" #R3 ", %[vo], s[76:79], s75 offen\n\ts_add_u32 s75, s75, %[pitch]\n\t"
+#define TB_LOAD(LD)                                                                                                          \
+    asm volatile(                                                                                                            \
+        "s_mov_b32 s76, %[d0]\n\ts_mov_b32 s77, %[d1]\n\ts_mov_b32 s78, %[nr]\n\ts_mov_b32 s79, 0x00020000\n\ts_mov_b32 s75, 0\n\t" \
+        "s_nop 4\n\t"                                                                                                        \
+        TB_LD4(LD, 64, 65, 66, 67) TB_LD4(LD, 68, 69, 70, 71) TB_LD4(LD, 72, 73, 74, 75) TB_LD4(LD, 76, 77, 78, 79)         \
+        TB_LD4(LD, 80, 81, 82, 83) TB_LD4(LD, 84, 85, 86, 87) TB_LD4(LD, 88, 89, 90, 91) TB_LD4(LD, 92, 93, 94, 95)         \
+        TB_LD4(LD, 96, 97, 98, 99) TB_LD4(LD, 100, 101, 102, 103) TB_LD4(LD, 104, 105, 106, 107) TB_LD4(LD, 108, 109, 110, 111) \
+        TB_LD4(LD, 112, 113, 114, 115) TB_LD4(LD, 116, 117, 118, 119) TB_LD4(LD, 120, 121, 122, 123) TB_LD4(LD, 124, 125, 126, 127) \
+        "s_waitcnt vmcnt(0)\n\t"                                                                                             \
+        :: [vo] "v"(voff), [d0] "s"(d0), [d1] "s"(d1), [nr] "s"(num_records), [pitch] "s"(row_pitch_bytes)                  \
+        : "memory", "scc", "s75", "s76", "s77", "s78", "s79", TB_WINDOW_REGS)
+    if constexpr (sizeof(PT) == 4) { TB_LOAD("buffer_load_dword"); } else { TB_LOAD("buffer_load_sbyte"); }
+#undef TB_LOAD
+#undef TB_LD4
+}
+
+// Up to 64 steps inside the window.  ti / tj: cursor (row register, lane); returns the number of steps taken, their codes in
+// lane order (rec), and why it stopped: 0 = 64 steps done, 1 = the cursor left the window (ti or tj is -1), 2 = P <= 0 (end).
+__device__ __forceinline__ int tb_walk(int& ti, int& tj, int& status, u32& rec) {
+    int k, c, t, keep;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 %[k], 0\n\t"
+        "s_mov_b32 %[st], 0\n\t"
+        "v_mov_b32 v63, 0\n"
+        "Ltb_loop_%=:\n\t"
+        "s_set_gpr_idx_on %[ti], 0x1\n\t"          /* src0 of the next VALU ops is v[64 + ti] */
+        "s_nop 0\n\t"
+        "v_mov_b32 v62, v64\n\t"
+        "s_set_gpr_idx_off\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 %[c], v62, %[tj]\n\t"
+        "s_nop 3\n\t"
+        "s_cmp_lt_i32 %[c], 1\n\t"
+        "s_cbranch_scc1 Ltb_end_%=\n\t"
+        "s_mov_b32 m0, %[k]\n\t"
+        "v_writelane_b32 v63, %[c], m0\n\t"
+        "s_add_u32 %[k], %[k], 1\n\t"
+        "s_and_b32 %[t], %[c], 1\n\t"
+        "s_sub_i32 %[ti], %[ti], %[t]\n\t"
+        "s_lshr_b32 %[t], %[c], 1\n\t"
+        "s_sub_i32 %[tj], %[tj], %[t]\n\t"
+        "s_or_b32 %[t], %[ti], %[tj]\n\t"
+        "s_cmp_lt_i32 %[t], 0\n\t"
+        "s_cbranch_scc1 Ltb_exit_%=\n\t"
+        "s_cmp_lt_u32 %[k], 64\n\t"
+        "s_cbranch_scc1 Ltb_loop_%=\n\t"
+        "s_branch Ltb_done_%=\n"
+        "Ltb_end_%=:\n\t"
+        "s_mov_b32 %[st], 2\n\t"
+        "s_branch Ltb_done_%=\n"
+        "Ltb_exit_%=:\n\t"
+        "s_mov_b32 %[st], 1\n"
+        "Ltb_done_%=:\n\t"
+        "s_mov_b32 m0, %[keep]\n\t"
+        "v_mov_b32 %[rec], v63\n\t"
+        : [k] "=&s"(k), [c] "=&s"(c), [t] "=&s"(t), [keep] "=&s"(keep), [st] "=&s"(status), [ti] "+s"(ti), [tj] "+s"(tj), [rec] "=v"(rec)
+        :
+        : "memory", "scc", "v62", "v63", TB_WINDOW_REGS);
+    return k;
+}
+
+__device__ __forceinline__ u32 tb_wave_prefix_sum(u32 v) {   // inclusive, 64 lanes
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);   // row_bcast:15
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);   // row_bcast:31
+    return v;
+}
+
+// One wave per problem (blockIdx.x = problem): walks problem k's P (at P + k * pstride, row stride M, rows1 rows) from start_pos
+// (>= 0) or res[k].max_pos, negates the path, writes its length to res[k].path_len, optionally the visited indices to
+// paths + k * cap and the index of the cell the walk stopped at (the first cell with P <= 0) to stop[k].
+template <typename PT>
+__global__ void __launch_bounds__(64) sw_traceback_wave(PT* __restrict__ P, int64_t M, int64_t rows1, int64_t pstride, int64_t start_pos,
+                                                        int64_t* __restrict__ paths, int64_t cap, sw_result* __restrict__ res, int64_t* __restrict__ stop) {
+    const int lane = threadIdx.x;
+    const int64_t k = blockIdx.x;
+    if (res[k].path_len < 0) return;            // the fill of this problem was aborted
+    PT* Pk = P + k * pstride;
+    int64_t* path = paths ? paths + k * cap : nullptr;
+    const int64_t pos_l = start_pos >= 0 ? start_pos : res[k].max_pos;
+    const int64_t pos = ((int64_t)__builtin_amdgcn_readfirstlane((int)(pos_l >> 32)) << 32) | (int64_t)(u32)__builtin_amdgcn_readfirstlane((int)(u32)pos_l);
+    int64_t gi = pos / M, gj = pos - gi * M, len = 0;
+    const int64_t total = rows1 * M;
+    for (;;) {
+        // window: rows r0 .. r0+63, columns c0 .. c0+63, the cursor in its bottom-right part
+        const int64_t r0 = gi > 63 ? gi - 63 : 0, c0 = gj > 63 ? gj - 63 : 0;
+        int ti = __builtin_amdgcn_readfirstlane((int)(gi - r0)), tj = __builtin_amdgcn_readfirstlane((int)(gj - c0));
+        const int64_t w0 = r0 * M + c0;
+        const uint64_t remain = (uint64_t)(total - w0) * sizeof(PT);
+        tb_load_window<PT>(Pk + w0, (u32)__builtin_amdgcn_readfirstlane((int)(remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)remain)),
+                           (u32)__builtin_amdgcn_readfirstlane((int)(u32)(M * (int64_t)sizeof(PT))), lane);
+        int status = 0;
+        do {
+            const int si = ti, sj = tj;            // cursor at the start of this run of steps
+            u32 rec;
+            const int n = tb_walk(ti, tj, status, rec);
+            if (n > 0) {
+                const u32 c = lane < n ? rec : 0u;
+                const u32 d = ((c & 1u) << 16) | (c >> 1);          // (rows up, columns left) of this step
+                const u32 before = tb_wave_prefix_sum(d) - d;       // moves made by the earlier steps
+                const int64_t idx = (r0 + si - (int64_t)(before >> 16)) * M + c0 + sj - (int64_t)(before & 0xffffu);
+                if (lane < n) {
+                    Pk[idx] = (PT)(-(int)c);
+                    if (path && len + lane < cap) path[len + lane] = idx;
+                }
+                len += n;
+            }
+        } while (status == 0);
+        gi = r0 + ti; gj = c0 + tj;
+        if (status == 2 || gi < 0 || gj < 0) break;
+    }
+    if (lane == 0) {
+        res[k].path_len = len;
+        if (stop) stop[k] = gi * M + gj;
+    }
+}
+template __global__ void sw_traceback_wave<int32_t>(int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*, int64_t*);
+template __global__ void sw_traceback_wave<signed char>(signed char*, int64_t, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*, int64_t*);
+
+}  // namespace swk

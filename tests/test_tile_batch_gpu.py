@@ -74,15 +74,24 @@ def test_batch_1024_pairs_config5_shape(engine, oracle, swamd):
 
 
 def test_batch_at_scale_shape_small_pairs(engine, oracle):
-    """The launch shape BASELINE config 5 uses at 100 000 pairs -- two strips per workgroup, several passes of the
-    resident grid over the strip groups, more than one 4096-pair chunk -- on 5000 small pairs: EVERY pair's H, P and
-    arg-max against the oracle."""
+    """5000 small pairs (ragged: 130 columns on 4-column lanes) through the one-pair-per-wave kernel, and once more through the
+    single-pair machinery (debug bit 16: the launch shape config 5 used before round 3 -- two strips per workgroup, several
+    passes of the resident grid, more than one 4096-pair chunk): EVERY pair's H, P and arg-max against the oracle."""
     rng = np.random.default_rng(11)
     npairs, cols, rows = 5000, 130, 70
     A = (rng.integers(0, 4, (npairs, cols)) + 65).astype(np.uint8)
     B = (rng.integers(0, 4, (npairs, rows)) + 65).astype(np.uint8)
     res, H, P = engine.batch(A, B, store=True)
-    assert engine.get_option("last_grid") == engine.get_option("num_cus")   # capped grid: many passes per workgroup
+    assert engine.get_option("last_batch_kernel") == 1
+    engine.set_option("debug_flags", 65536)
+    try:
+        res_o, H_o, P_o = engine.batch(A, B, store=True)
+        assert engine.get_option("last_batch_kernel") == 0
+        assert engine.get_option("last_grid") == engine.get_option("num_cus")   # capped grid: many passes per workgroup
+    finally:
+        engine.set_option("debug_flags", 0)
+    assert bool((res_o == res).all()) and bool((H_o == H).all()) and bool((P_o == P).all())
+    del res_o, H_o, P_o
     res, H, P = res.cpu().numpy(), H.cpu().numpy(), P.cpu().numpy()
     assert (res[:, 2] == 0).all()
     for k in range(npairs):

@@ -29,5 +29,28 @@ nprod = s2.count("SW_PRODUCER_PATH_BEGIN")
 for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)", s2):
     if int(m.group(1)) != 0:
         print("scratch in use (systolic):", m.group(0)); sys.exit(1)
+# sw_traceback.hip keeps a 64-row window of P in the LITERAL registers v64..v127 (+ v62 / v63) ACROSS asm statements: no
+# compiler-generated instruction may touch them; sw_batch.hip must not spill
+def dev_asm(name):
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++20", "-S", "--cuda-device-only",
+                        os.path.join(here, "..", "smith-waterman_amd", "csrc", name), "-o", os.path.join(td, "k.s")], check=True, stderr=subprocess.DEVNULL)
+        return open(os.path.join(td, "k.s")).read()
+s3 = dev_asm("sw_traceback.hip")
+inasm, bad3 = False, []
+for ln in s3.splitlines():
+    t = ln.strip()
+    if t.startswith(";;#ASMSTART"): inasm = True; continue
+    if t.startswith(";;#ASMEND"): inasm = False; continue
+    if inasm or not t or t[0] in ";." or t.endswith(":"): continue
+    regs = [int(x) for x in re.findall(r"\bv(\d+)\b", t)]
+    for a, b in re.findall(r"v\[(\d+):(\d+)\]", t): regs += list(range(int(a), int(b) + 1))
+    if any(r >= 62 for r in regs): bad3.append(ln)
+if bad3:
+    print("compiler code touches the traceback window registers v62..v127:\n" + "\n".join(bad3[:10])); sys.exit(1)
+for txt, what in ((s3, "traceback"), (dev_asm("sw_batch.hip"), "batch")):
+    for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)", txt):
+        if int(m.group(1)) != 0:
+            print(f"scratch in use ({what}):", m.group(0)); sys.exit(1)
 n = len(re.findall(r"global_load_dwordx2 v\[126:127\]", s))
-print(f"check_isa ok: {n} prefetch sites, v126/v127 private; {nprod} producer paths keep v100..v120 private; no scratch")
+print(f"check_isa ok: {n} prefetch sites, v126/v127 private; {nprod} producer paths keep v100..v120 private; traceback window v62..v127 private; no scratch")
