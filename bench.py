@@ -34,10 +34,10 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def _best_of(cmd, n, env=None):
+def _best_of(cmd, n, env=None, timeout=120):
     best = None
     for _ in range(n):
-        t = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env).stdout
+        t = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env).stdout
         m = re.search(r"scoring matrix computation:\s*([0-9.]+)", t)
         if m:
             s = float(m.group(1))
@@ -45,9 +45,27 @@ def _best_of(cmd, n, env=None):
     return best
 
 
+def _clocks():
+    """Current sclk / mclk of the GPUs this process can see (sysfs; the entry marked * is the active level)."""
+    out = {}
+    import glob
+    for kind in ("sclk", "mclk"):
+        vals = []
+        for f in sorted(glob.glob(f"/sys/class/drm/card*/device/pp_dpm_{kind}")):
+            try:
+                cur = [ln for ln in open(f).read().splitlines() if ln.rstrip().endswith("*")]
+                if cur:
+                    vals.append(cur[0].split(":")[1].replace("*", "").strip())
+            except OSError:
+                pass
+        out[kind] = vals
+    return out
+
+
 def cpu_baseline(cols, rows):
     """The REAL reference programs (oracle/_ref, built from /root/reference in the build container) timed on this box's
-    host cores, best of 3 like the reference's run-v1.sh:33; falls back to the C port (oracle/liboracle.so)."""
+    host cores; falls back to the C port (oracle/liboracle.so).  Every leg is bounded (a few seconds): serial_smithW on the
+    full workload best of 3 like run-v1.sh:33, the OpenMP variants on bounded samples."""
     ref = os.path.join(ROOT, "oracle", "_ref", "serial_smithW")
     out = {}
     ncores = len(os.sched_getaffinity(0))
@@ -57,26 +75,32 @@ def cpu_baseline(cols, rows):
                "sample": f"serial_smithW {cols} {rows} (the full workload, fill loop only), best of 3: {sec:.3f} s"}
         omp = os.path.join(ROOT, "oracle", "_ref", "omp_smithW-v1")
         if os.path.exists(omp):
-            # one barrier per anti-diagonal: more threads are not faster.  Best of 3 with 16 threads, and ONE run on a bounded
-            # sample with every core this process may use (the reference's own scripts use all of them, run-v1.sh:33)
+            # one barrier per anti-diagonal: more threads are not faster.  Best of 3 with 16 threads; with every hardware thread
+            # (what the reference's own scripts use, run-v1.sh:33) the same program is ~1000x slower: ONE run of a 1024^2 sample
             env = dict(os.environ, OMP_NUM_THREADS="16", OMP_PROC_BIND="close")
             sec = _best_of([omp, str(cols), str(rows)], 3, env)
             if sec:
                 out["omp"] = {"value": cols * rows / sec / 1e9, "unit": "GCUPS", "cores": 16, "kind": "reference",
                               "sample": f"omp_smithW-v1-refinedOrig -DSKIP_BACKTRACK {cols} {rows}, 16 threads, best of 3: {sec:.3f} s"}
             if ncores > 16:
-                n = min(cols, 4096)
+                n = min(cols, 1024)
                 env = dict(os.environ, OMP_NUM_THREADS=str(ncores), OMP_PROC_BIND="close")
-                sec = _best_of([omp, str(n), str(n)], 1, env)
+                try:
+                    sec = _best_of([omp, str(n), str(n)], 1, env, timeout=20)
+                except subprocess.TimeoutExpired:
+                    sec = None
                 if sec:
                     out["omp_all_cores"] = {"value": n * n / sec / 1e9, "unit": "GCUPS", "cores": ncores, "kind": "reference",
                                             "sample": f"omp_smithW-v1-refinedOrig -DSKIP_BACKTRACK {n} {n}, all {ncores} hardware threads: {sec:.3f} s"}
         ompc = os.path.join(ROOT, "oracle", "_ref", "omp_smithW")
         if os.path.exists(ompc):
-            # omp_smithW.c takes an `omp critical` per cell (omp_smithW.c:384-387): a bounded sample, 4096 x 4096
+            # omp_smithW.c takes an `omp critical` per cell (omp_smithW.c:384-387): a bounded sample, 2048 x 2048
             env = dict(os.environ, OMP_NUM_THREADS=str(min(ncores, 16)), OMP_PROC_BIND="close")
-            n = min(cols, 4096)
-            sec = _best_of([ompc, str(n), str(n)], 1, env)
+            n = min(cols, 2048)
+            try:
+                sec = _best_of([ompc, str(n), str(n)], 1, env, timeout=20)
+            except subprocess.TimeoutExpired:
+                sec = None
             if sec:
                 out["omp_critical"] = {"value": n * n / sec / 1e9, "unit": "GCUPS", "cores": min(ncores, 16), "kind": "reference",
                                        "sample": f"omp_smithW (per-cell critical arg-max) {n} {n}, {min(ncores, 16)} threads: {sec:.3f} s"}
@@ -106,11 +130,16 @@ def chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows):
     S2 = int(eng.get_option("last_strips2"))   # > 0: the two-column kernel ran (126 columns per strip)
     if S2 > 0:
         S = S2
-    t = dbg.cpu().numpy()[:2 * S].reshape(S, 2).astype(np.float64) * 10.0   # 100 MHz ticks -> ns
+    raw = dbg.cpu().numpy()
+    t = raw[:2 * S].reshape(S, 2).astype(np.float64) * 10.0   # 100 MHz ticks -> ns
     steps = rows + 63 + (S - 1)
     tau = (t[0, 1] - t[0, 0]) / max(1, steps)
     lag = float(np.diff(t[:, 1]).mean()) if S > 1 else 0.0
-    return tau, lag
+    # shader clock while the kernel ran: s_memtime ticks per s_memrealtime tick (100 MHz), stamped around strip 0's producer
+    ghz = None
+    if S2 > 0 and raw[6 * S + 17] > raw[6 * S + 16] and t[0, 1] > t[0, 0]:
+        ghz = float(raw[6 * S + 17] - raw[6 * S + 16]) / (t[0, 1] - t[0, 0])
+    return tau, lag, ghz
 
 
 def traffic_for(workload_key, kernel=None):
@@ -152,8 +181,18 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
         dt = time.perf_counter() - t0
         return dt, [e0.elapsed_time(e1) for e0, e1 in evs]
 
+    clocks0 = _clocks()
     # (1) a plain first allocation: what a caller of sw_device_malloc gets
     first = eng.alloc(cols, rows, h_dtype, p_dtype)
+    # pre-heat: at least --preheat seconds of back-to-back fills before anything is timed (a freshly leased GPU idles at
+    # 95 MHz; the W warm-up steps of the contract follow, inside timed())
+    t_heat = time.perf_counter()
+    nheat = 0
+    while time.perf_counter() - t_heat < args.preheat:
+        for _ in range(20):
+            eng.fill_into(first, d_a, d_b)
+        torch.cuda.synchronize()
+        nheat += 20
     f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     first.H.fill_(0); torch.cuda.synchronize()
     f0.record()
@@ -172,7 +211,8 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
         out, placement_ms = eng.alloc_outputs(d_a, d_b, cols, rows, h_dtype, p_dtype, trials=args.placement_trials)
     dt, kern_ms = timed(out, args.steps, args.warmup)
     res = out.result()
-    tau_ns, lag_ns = chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows) if args.engine == 0 else (0.0, 0.0)
+    tau_ns, lag_ns, shader_ghz = chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows) if args.engine == 0 else (0.0, 0.0, None)
+    clocks1 = _clocks()
     if world > 1:
         tmax = torch.tensor([dt], device=f"cuda:{local}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -194,7 +234,8 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
                    "per_gpu": "one pair per GPU" + (" (replicas)" if world > 1 else ""), "max_pos": res["max_pos"], "max_score": res["max_score"],
                    "grid": eng.get_option("last_grid"), "strips": int(eng.get_option("last_strips2")) or eng.get_option("last_strips"),
                    "output_buffers": "sw_alloc_outputs (C-ABI allocator, placement chosen by trial fills)" if placement_ms is not None else "plain first allocation",
-                   "placement_trials_ms": placement_ms, "value_first_allocation": value_first,
+                   "placement_trials_ms": placement_ms, "value_first_allocation": value_first, "preheat_fills": nheat,
+                   "clocks_before": clocks0, "clocks_after": clocks1, "shader_clock_ghz_in_kernel": shader_ghz,
                    "ms_first_allocation": sum(ms_first) / len(ms_first)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
@@ -264,35 +305,72 @@ def run_bands(args, sw, eng, torch, dist, rank, world, local):
     print(json.dumps(line), flush=True)
 
 
+VALU_PEAK_GWIPS = 1024 * 2.4 / 4.0   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 clk per SIMD at 2.4 GHz (G wave-instr/s)
+# instructions the batch kernel (sw_batch_wave<16, PB>) issues per step = one row x 1024 columns of a pair, counted in its ISA
+# (scripts/count_batch_isa.py): score + exact arg-max only / int8 P stored / int32 P stored; H stored adds 5
+BATCH_INSTR_PER_STEP = {0: 84, 1: 186, 4: 176}
+
+
 def run_batch(args, sw, eng, torch, dist, rank, world, local):
     import numpy as np
     cols, rows, npairs = args.cols, args.rows, args.pairs
-    A = np.stack([sw.generate(cols, rows, 1 + rank * npairs + k)[0] for k in range(npairs)])
-    B = np.stack([sw.generate(cols, rows, 1 + rank * npairs + k)[1] for k in range(npairs)])
+    gen = [sw.generate(cols, rows, 1 + rank * npairs + k) for k in range(npairs)]
+    A, B = np.stack([g[0] for g in gen]), np.stack([g[1] for g in gen])
     p_dtype = torch.int8 if args.p8 else None
-    step = lambda: eng.batch(A, B, store=args.store, p_dtype=p_dtype, store_h=not args.no_h, traceback=args.traceback)
-    for _ in range(args.warmup):
+    d_a, d_b, _, _ = eng.batch_to_device(A, B)          # the sequences are resident in HBM before anything is timed
+    out = None
+
+    def step():
+        nonlocal out
+        r = eng.batch_device(d_a, d_b, cols, rows, store=args.store, p_dtype=p_dtype, store_h=not args.no_h, traceback=args.traceback, out=out)
+        out = r[:3]
+        return r
+
+    for _ in range(max(1, args.warmup)):
         step()
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for _ in range(args.steps):
         step()
+    e1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank != 0:
         return
     cells = npairs * cols * rows
     bpc = ((0 if args.no_h else 4) + (1 if args.p8 else 4)) if args.store else 0
-    what = f"{npairs} independent {cols}x{rows} pairs (pair k seeded 1+k) in one call: "
+    wave = eng.get_option("last_batch_kernel") == 1
+    what = f"{npairs} independent {cols}x{rows} pairs (pair k seeded 1+k) in one call, sequences resident in HBM: "
     what += (f"{'int32 H + ' if not args.no_h else ''}{'int8' if args.p8 else 'int32'} P stored ({bpc} B/cell)" if args.store else "score + exact maxPos only (no matrices)")
     what += ", per-pair traceback" if args.traceback else ""
     line = {"metric": "GCUPS (DP cell updates/s)", "value": args.steps * cells / dt / 1e9, "unit": "GCUPS", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic", "config": {"workload": what + " (host-to-device copy of the sequences included)", "mode": "batch"}}
-    if bpc:
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": what, "mode": "batch", "kernel": "sw_batch_wave (one pair per wave)" if wave else "sw_systolic (single-pair machinery)",
+                       "device_ms_per_step": e0.elapsed_time(e1) / args.steps}}
+    if wave:
+        pb = (1 if args.p8 else 4) if args.store else 0
+        ipstep = BATCH_INSTR_PER_STEP[pb] + (5 if (args.store and not args.no_h) else 0)
+        steps = npairs * (rows + 64) * -(-cols // 1024)
+        ach = steps * ipstep / (dt / args.steps) / 1e9
+        line["roofline"] = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GWIPS, "traffic": None,
+                            "kernel": f"sw_batch_wave<16,{pb}>", "instructions_per_1024_cell_step": ipstep,
+                            "note": "integer max/add recurrence: no contraction, so no MFMA; the bound is vector issue (1 wave64 instruction per 4 clk per SIMD)"}
+        if bpc:
+            hb = bpc * cells / (dt / args.steps) / 1e9
+            line["roofline"]["hbm"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS, "algorithmic_bytes_per_cell": bpc}
+    elif bpc:
         ach = bpc * cells / (dt / args.steps) / 1e9
         line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                             "kernel": "sw_systolic", "algorithmic_bytes_per_cell": bpc}
+    if not args.no_cpu:
+        ref = os.path.join(ROOT, "oracle", "_ref", "serial_smithW")
+        if os.path.exists(ref):   # the reference handles one pair per process: serial_smithW <cols> <rows>, best of 5 (fill loop only)
+            sec = _best_of([ref, str(cols), str(rows)], 5)
+            line["cpu_baseline"] = {"value": cols * rows / sec / 1e9, "unit": "GCUPS", "cores": 1, "kind": "reference",
+                                    "sample": f"serial_smithW {cols} {rows} (one pair of the batch), best of 5: {sec * 1e3:.2f} ms per pair"}
     print(json.dumps(line), flush=True)
 
 
@@ -327,7 +405,20 @@ def main():
     ap.add_argument("--xcd-order", type=int, default=0, help="systolic: 1 = neighbouring strip groups on one XCD")
     ap.add_argument("--debug-flags", type=int, default=0)
     ap.add_argument("--max-blocks", type=int, default=0)
+    ap.add_argument("--batch-lds", type=int, default=0, help="batch kernel: dynamic LDS bytes per workgroup (caps the waves per CU; experiments)")
+    ap.add_argument("--preheat", type=float, default=0.5, help="pair mode: seconds of untimed back-to-back fills before the warm-up steps")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as CHILD processes, before this process has
+        # touched the GPU (it never does), and leave with their exit code
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
@@ -336,6 +427,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     ndev = torch.cuda.device_count()
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for another GPU count", file=sys.stderr)
+        sys.exit(2)
+    if world > 1 and args.backend == "nccl" and ndev < world:
+        print(f"bench.py: --gpus {world} over RCCL needs {world} GPUs, this box has {ndev} (--backend gloo rehearses with ranks sharing GPUs)", file=sys.stderr)
+        sys.exit(3)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -351,7 +448,7 @@ def main():
         args.max_blocks = max(8, eng.get_option("num_cus") // -(-world // max(1, ndev)) - 16)
     eng.set_option("engine", args.engine)
     for name, v in (("importers", args.importers), ("store_policy", args.store_policy), ("strips_per_group", args.ns), ("consumers", args.nc),
-                    ("debug_flags", args.debug_flags), ("max_blocks", args.max_blocks), ("xcd_order", args.xcd_order)):
+                    ("debug_flags", args.debug_flags), ("max_blocks", args.max_blocks), ("xcd_order", args.xcd_order), ("batch_lds", args.batch_lds)):
         if v:
             eng.set_option(name, v)
     mode = args.mode

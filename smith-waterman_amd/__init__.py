@@ -191,13 +191,24 @@ class _Outputs:
 
     def __init__(self, engine, dH, dP):
         self.engine, self.dH, self.dP = engine, dH, dP
+        engine._outputs.append(self)
 
-    def __del__(self):
+    def free(self):
+        """sw_free_outputs, once (Engine.close() frees whatever is still alive: the pair must not outlive its context)."""
+        if self.dH is None and self.dP is None:
+            return
         try:
             if self.engine._h:
                 lib().sw_free_outputs(self.engine._h, self.dH, self.dP)
         except Exception:
             pass
+        self.dH = self.dP = None
+        try:
+            self.engine._outputs.remove(self)
+        except ValueError:
+            pass
+
+    __del__ = free
 
 
 class Engine:
@@ -212,11 +223,14 @@ class Engine:
         self.device = device
         torch.cuda.set_device(device)
         h = _vp()
+        self._outputs = []          # live sw_alloc_outputs pairs (freed at the latest by close())
         _check(lib().sw_create(device, ctypes.byref(h)))
         self._h = h
 
     def close(self):
         if getattr(self, "_h", None):
+            for o in list(getattr(self, "_outputs", [])):
+                o.free()
             try:
                 lib().sw_destroy(self._h)
             except Exception:  # interpreter shutdown: module globals are already gone
@@ -334,6 +348,11 @@ class Engine:
         store: write P (int32, or int8 with p_dtype=torch.int8) and -- unless store_h is False -- H of every pair.
         traceback: also run backtrack() per pair (needs P); results[:, 2] then holds the path lengths.
         Returns (results[npairs,3] int64 tensor, H, P) -- plus the paths tensor (npairs, cols+rows+2) when want_paths."""
+        d_a, d_b, cols, rows = self.batch_to_device(a_all, b_all)
+        return self.batch_device(d_a, d_b, cols, rows, scores, store, p_dtype, store_h, traceback, want_paths)
+
+    def batch_to_device(self, a_all, b_all):
+        """Host sequences of a batch -> device tensors in the layout sw_batch_device wants (rows of b padded to 16 bytes)."""
         t = self.torch
         a_all = np.ascontiguousarray(a_all, np.uint8)
         b_all = np.ascontiguousarray(b_all, np.uint8)
@@ -344,15 +363,30 @@ class Engine:
         d_a = t.from_numpy(a_all).to(dev)
         bpad = np.zeros((npairs, bstr), np.uint8)
         bpad[:, :rows] = b_all
-        d_b = t.from_numpy(bpad).to(dev)
-        res = t.zeros((npairs, 3), dtype=t.int64, device=dev)
-        H = P = None
-        if store:
-            if store_h is None or store_h:
-                H = t.empty((npairs, rows + 1, cols + 1), dtype=t.int32, device=dev)
-            P = t.empty((npairs, rows + 1, cols + 1), dtype=p_dtype or t.int32, device=dev)
+        return d_a, t.from_numpy(bpad).to(dev), cols, rows
+
+    def batch_device(self, d_a, d_b, cols: int, rows: int, scores=DEFAULT_SCORES, store: bool = False, p_dtype=None, store_h=None,
+                     traceback: bool = False, want_paths: bool = False, out=None):
+        """sw_batch_device_ex (+ sw_batch_traceback_device) on sequences already resident in HBM (batch_to_device).  `out`:
+        (res, H, P) tensors of an earlier call to write into again."""
+        t = self.torch
+        npairs = d_a.shape[0]
+        dev = f"cuda:{self.device}"
+        if out is not None:
+            res, H, P = out
+        else:
+            res = t.zeros((npairs, 3), dtype=t.int64, device=dev)
+            H = P = None
+            if store:
+                if store_h is None or store_h:
+                    H = t.empty((npairs, rows + 1, cols + 1), dtype=t.int32, device=dev)
+                P = t.empty((npairs, rows + 1, cols + 1), dtype=p_dtype or t.int32, device=dev)
+                if os.environ.get("SW_P_SHIFT") and P.dtype == t.int8:   # alignment experiments: P starts SW_P_SHIFT bytes off a 256-byte boundary
+                    flat = t.empty(P.numel() + 256, dtype=t.int8, device=dev)
+                    sh = int(os.environ["SW_P_SHIFT"])
+                    P = flat[sh:sh + P.numel()].view(npairs, rows + 1, cols + 1)
         sc = _Scores(*scores)
-        _check(lib().sw_batch_device_ex(self._h, d_a.data_ptr(), cols, cols, d_b.data_ptr(), bstr, rows, npairs, ctypes.byref(sc),
+        _check(lib().sw_batch_device_ex(self._h, d_a.data_ptr(), d_a.shape[1], cols, d_b.data_ptr(), d_b.shape[1], rows, npairs, ctypes.byref(sc),
                                         H.data_ptr() if H is not None else None, P.data_ptr() if P is not None else None,
                                         P.element_size() if P is not None else 4, res.data_ptr(), self._stream()))
         paths = None

@@ -63,6 +63,7 @@ struct sw_ctx {
     int64_t opt_max_blocks = 0;         // 0 -> 2 * CUs
     unsigned char* d_bcodes = nullptr; size_t bcodes_cap = 0;   // batch kernel: padded letter codes of every pair's b
     int* d_bnd = nullptr; size_t bnd_cap = 0;                   // batch kernel: boundary columns between strips (ints)
+    int64_t opt_batch_lds = 0;          // batch kernel: dynamic LDS bytes per workgroup (caps the waves per CU; experiments)
     int64_t last_batch_kernel = 0;      // 1: the last sw_batch_device call ran on sw_batch_wave (one pair per wave)
     int64_t last_grid = 0, last_strips = 0;
     int64_t last_strips2 = 0;           // strips of the two-column kernel in the last launch (0: not launched)
@@ -120,6 +121,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "xcd_order")) { c->opt_xcd_order = v ? 1 : 0; return SW_OK; }
     if (!strcmp(name, "importers")) { if (v < 0 || v > 8) return SW_EINVAL; c->opt_importers = v; return SW_OK; }
     if (!strcmp(name, "debug_buf")) { c->opt_dbg_ptr = v; return SW_OK; }
+    if (!strcmp(name, "batch_lds")) { c->opt_batch_lds = v < 0 ? 0 : v; return SW_OK; }
     if (!strcmp(name, "band_wait_ms")) { c->opt_band_wait_ms = v > 0 ? v : 20000; return SW_OK; }
     if (!strcmp(name, "debug_epoch8")) { c->epoch8 = (unsigned)(v & 255); return SW_OK; }   // development aid: next launch tag = v + 1
     if (!strcmp(name, "engine")) {
@@ -525,7 +527,7 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
         hipLaunchKernelGGL(swk::sw_alpha_scan, dim3(nblk), dim3(256), 0, stream, ua, cols, a_stride, ub, rows, b_stride, npairs, (unsigned int*)c->d_alpha);
     }
     const int front = 64;
-    const int64_t per = ((rows + front + 80 + 15) / 16) * 16;
+    const int64_t per = ((rows + front + 80 + 72 + 15) / 16) * 16;   // (+40: the drain steps of the delayed int8 P stores read on)
     const int C = cols <= 256 ? 4 : cols <= 512 ? 8 : 16;
     const int64_t nstrips = (cols + 64 * C - 1) / (64 * C);
     const int64_t bnd_per = nstrips > 1 ? ((rows + 160 + 3) / 4) * 4 : 0;
@@ -544,8 +546,10 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
         c->d_bnd = nullptr; c->bnd_cap = 0;
         if (hipMalloc((void**)&c->d_bnd, (size_t)(chunk * bnd_per) * 4) != hipSuccess) { set_err("workspace allocation failed"); return SW_ENOMEM; }
         c->bnd_cap = (size_t)(chunk * bnd_per);
-        HIP_TRY(hipMemsetAsync(c->d_bnd, 0, c->bnd_cap * 4, stream));
     }
+    // lane 0 of a later strip also reads boundary entries below the matrix that no strip of THIS call writes: they must not hold
+    // an earlier call's scores (a cell outside the matrix may never exceed the cells of the matrix, see the arg-max in sw_batch.hip)
+    if (bnd_per) HIP_TRY(hipMemsetAsync(c->d_bnd, 0, (size_t)(chunk * bnd_per) * 4, stream));
     const int64_t cells = (cols + 1) * (rows + 1);
     for (int64_t k0 = 0; k0 < npairs; k0 += chunk) {
         const int64_t n = std::min(chunk, npairs - k0);
@@ -568,9 +572,10 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
         bp.match = sc->match; bp.mismatch = sc->mismatch; bp.ngap = -sc->gap;
         bp.bnd = c->d_bnd; bp.bnd_pstride = bnd_per;
         bp.results = d_results + k0;
+        bp.debug = (int)(c->opt_debug & 7);   // bit 0: no matrix stores, bit 1: nt stores, bit 2: sc1 stores (experiments)
         const int pb = d_P ? p_elem_bytes : 0;
-        const dim3 grid((unsigned)((n + 3) / 4)), block(256);
-#define SB_LAUNCH(CC, PP) if (C == CC && pb == PP) hipLaunchKernelGGL((swk::sw_batch_wave<CC, PP>), grid, block, 0, stream, bp);
+        const dim3 grid((unsigned)((n + 3) / 4)), block(256);   // 4 pairs (waves) per workgroup
+#define SB_LAUNCH(CC, PP) if (C == CC && pb == PP) hipLaunchKernelGGL((swk::sw_batch_wave<CC, PP>), grid, block, (size_t)c->opt_batch_lds, stream, bp);
         SB_LAUNCH(4, 0) SB_LAUNCH(4, 1) SB_LAUNCH(4, 4) SB_LAUNCH(8, 0) SB_LAUNCH(8, 1) SB_LAUNCH(8, 4) SB_LAUNCH(16, 0) SB_LAUNCH(16, 1) SB_LAUNCH(16, 4)
 #undef SB_LAUNCH
         HIP_TRY(hipGetLastError());
@@ -704,11 +709,13 @@ int sw_align_auto(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t
 
 static int traceback_launch(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path, int64_t path_cap,
                             sw_result* d_result, int64_t* d_stop, hipStream_t stream) {
+    // a big matrix is in no cache when the walk starts: a second wave reads ahead of the walking one (csrc/sw_traceback.hip)
+    const dim3 block((double)(cols + 1) * (double)(rows + 1) * p_elem_bytes > 64.0e6 ? 128 : 64);
     if (p_elem_bytes == 4)
-        hipLaunchKernelGGL(swk::sw_traceback_wave<int32_t>, dim3(1), dim3(64), 0, stream, (int32_t*)d_P, cols + 1, rows + 1, (int64_t)0, max_pos, d_path,
+        hipLaunchKernelGGL(swk::sw_traceback_wave<int32_t>, dim3(1), block, 0, stream, (int32_t*)d_P, cols + 1, rows + 1, (int64_t)0, max_pos, d_path,
                            d_path ? path_cap : 0, d_result, d_stop);
     else
-        hipLaunchKernelGGL(swk::sw_traceback_wave<signed char>, dim3(1), dim3(64), 0, stream, (signed char*)d_P, cols + 1, rows + 1, (int64_t)0, max_pos, d_path,
+        hipLaunchKernelGGL(swk::sw_traceback_wave<signed char>, dim3(1), block, 0, stream, (signed char*)d_P, cols + 1, rows + 1, (int64_t)0, max_pos, d_path,
                            d_path ? path_cap : 0, d_result, d_stop);
     HIP_TRY(hipGetLastError());
     return SW_OK;

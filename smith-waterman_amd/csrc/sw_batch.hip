@@ -24,7 +24,10 @@ namespace swk {
 typedef unsigned int u32;
 typedef unsigned long long u64;
 
-constexpr u32 SB_OOB = 0xFFFFFF00u;      // buffer offset beyond every descriptor: the store is dropped
+constexpr u32 SB_OOB = 0xFFFFFF00u;
+#ifndef SB_RUN
+#define SB_RUN 256                         // bytes of one row that a lane group stores with one instruction (int8 P)
+#endif      // buffer offset beyond every descriptor: the store is dropped
 
 // Letter codes of every pair's b (rank of the byte value among the values present in the batch, 0..7) in a padded copy:
 // bcode[pair * per + front + i] = code(b[i]); 0x0D outside the sequence -- as a v_perm_b32 selector byte that yields 0xFF, the
@@ -99,6 +102,9 @@ __device__ __forceinline__ void sb_for(F&& f) {
 
 typedef int sb_v4i __attribute__((ext_vector_type(4)));
 typedef int sb_v2i __attribute__((ext_vector_type(2)));
+template <int C> struct SbSeg { typedef int type; };            // C packed P codes of one lane and row
+template <> struct SbSeg<8> { typedef sb_v2i type; };
+template <> struct SbSeg<16> { typedef sb_v4i type; };
 
 // C: columns per lane (4, 8, 16); PB: bytes per P element written (0: P not written, 1: int8, 4: int32)
 template <int C, int PB>
@@ -129,7 +135,10 @@ __global__ void __launch_bounds__(256) sw_batch_wave(BatchParams p) {
     const u32 dmm = ((u32)(unsigned char)(signed char)p.match) ^ ((u32)(unsigned char)(signed char)p.mismatch);
     u64 kbest = 0;         // per lane: best (score << 40 | MASK - index) over the strips done
     int sbest = 1;         // wave-uniform: highest valid H seen so far (at least 1: zeros never count)
-    const int G = (rows + 64 + 3) / 4;
+    // steps 0 .. rows + 63 (lane 63's last row); delayed int8 P stores drain for up to 128 / C + 1 more
+    const int G = (rows + 64 + (PB == 1 ? SB_RUN / C + 1 : 0) + 3) / 4;
+    __shared__ __attribute__((aligned(16))) unsigned char sb_ring[PB == 1 ? 4 * 64 * SB_RUN : 16];   // (4 waves per workgroup; 2-wave workgroups were slower: 1963 vs 2148 GCUPS)
+    unsigned char* const ring = sb_ring + (PB == 1 ? wave * 64 * SB_RUN + lane * C : 0);
 
     for (int st = 0; st < nstrips; ++st) {
         const int c0 = st * 64 * C + lane * C + 1;
@@ -150,12 +159,19 @@ __global__ void __launch_bounds__(256) sw_batch_wave(BatchParams p) {
         int h[C];
 #pragma unroll
         for (int k = 0; k < C; ++k) h[k] = 0;
-        int diag0 = 0, lbest = 0, lidx = 0;
+        int diag0 = 0, lbest = 0, lk = 0, lstep = 0;
         // output offsets of my row segment at step u = 0 (row -lane): wraps to a huge unsigned offset above the matrix, runs past
         // the descriptor below it -- stores outside rows 0..rows are dropped by the bounds check.  (Row 0 is stored too: H = P = 0.)
-        const bool full = nval == C;
+        const bool full = nval == C && !(p.debug & 1);   // (debug bit 0: drop the matrix stores, timing experiments)
         u32 voffH = (full && wh) ? (u32)((-lane * M + c0) * 4) : SB_OOB;
         u32 voffP = (full && wp) ? (u32)((-lane * M + c0) * PB) : SB_OOB;
+        // int8 P: delayed stores through the LDS ring (see the store below): this lane's piece leaves 1 + dly steps late
+        constexpr int GS = PB == 1 ? SB_RUN / C : 1;
+        const int dly = GS - 1 - (lane & (GS - 1));
+        const int dslot = (GS - dly) & (GS - 1);                     // the slot read at step u is (u - dly) mod GS
+        if (PB == 1 && full) voffP -= (u32)((1 + dly) * M);
+        typedef typename SbSeg<C>::type SegT;
+        SegT dseg = {};
         const bool col0 = st == 0 && lane == 0;
         u32 voffH0 = (wh && col0) ? 0u : SB_OOB, voffP0 = (wp && col0) ? 0u : SB_OOB;   // column 0
         // (lanes that do not store keep their out-of-range offset: pitch 0)
@@ -237,15 +253,21 @@ __global__ void __launch_bounds__(256) sw_batch_wave(BatchParams p) {
                     }
                     voffP += pitchP; voffP0 += pitchP0;
                 } else if constexpr (PB == 1) {
-                    if constexpr (C == 16) {
-                        const sb_v4i v = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rP, (int)voffP, 0, 0);
-                    } else if constexpr (C == 8) {
-                        const sb_v2i v = {(int)pk[0], (int)pk[1]};
-                        __builtin_amdgcn_raw_buffer_store_b64(v, rP, (int)voffP, 0, 0);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b32((int)pk[0], rP, (int)voffP, 0, 0);
-                    }
+                    // Whole 128-byte runs instead of 64 scattered C-byte pieces per store.  Lane l's piece of row r is ready at
+                    // step r + l, its neighbours' one step apart each: stored at once, a wave's store instruction touches 64
+                    // different rows, and the L2 writes every piece to HBM on its own (measured: 3.3x the bytes, the fill at
+                    // half speed).  So every lane parks its piece in a ring in LDS and stores the one it produced d = GS-1 - l%GS
+                    // steps ago (+1 step: the read-back is used a step later, its latency behind the next row's arithmetic):
+                    // the GS = SB_RUN/C lanes of a group then store pieces of the SAME row with one instruction -- SB_RUN contiguous bytes.
+                    SegT seg;
+                    if constexpr (C == 16) seg = SegT{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+                    else if constexpr (C == 8) seg = SegT{(int)pk[0], (int)pk[1]};
+                    else seg = (int)pk[0];
+                    if constexpr (C == 16) __builtin_amdgcn_raw_buffer_store_b128(dseg, rP, (int)voffP, 0, 0);
+                    else if constexpr (C == 8) __builtin_amdgcn_raw_buffer_store_b64(dseg, rP, (int)voffP, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b32(dseg, rP, (int)voffP, 0, 0);
+                    *(SegT*)(ring + (u & (GS - 1)) * (64 * C)) = seg;
+                    dseg = *(const SegT*)(ring + ((u + dslot) & (GS - 1)) * (64 * C));
                     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)0, rP, (int)voffP0, 0, 0);
                     if (ragged) {
 #pragma unroll
@@ -256,28 +278,32 @@ __global__ void __launch_bounds__(256) sw_batch_wave(BatchParams p) {
                     voffP += pitchP; voffP0 += pitchP0;
                 }
                 if (bw) __builtin_amdgcn_raw_buffer_store_b32(h[C - 1], rB, lane == 63 ? 4 : (int)SB_OOB, 4 * u, 0);   // row u - 63 at index row + 64
-                // ---- arg-max: the row maximum against the wave's best; the cell is looked for only when it may matter
+                // ---- arg-max: the row maximum against the wave's best so far; only a step that reaches it looks for the cell.
+                // (Cells outside the matrix need no masking here: such a cell never exceeds a cell of the matrix computed before
+                // it -- it scores -1 against everything -- so it cannot raise `sbest` and a record it leaves in a lane loses
+                // against a real one at the end.)
                 int m = h[0];
 #pragma unroll
                 for (int k = 1; k + 1 < C; k += 2) m = max(max(m, h[k]), h[k + 1]);
                 m = max(m, h[C - 1]);
                 if (__builtin_amdgcn_ballot_w64(m >= sbest) != 0) {
-                    const int r = u - lane;
-                    const bool rv = r >= 1 && r <= rows;
-                    int mv = 0;
+                    sbest = max(sbest, sb_wave_max(m));
+                    int kk = 0;                                   // first column of my row that holds its maximum
 #pragma unroll
-                    for (int k = 0; k < C; ++k) {
-                        const int v = (rv && k < nval) ? h[k] : 0;
-                        if (v > lbest) { lbest = v; lidx = r * M + c0 + k; }
-                        mv = max(mv, v);
-                    }
-                    sbest = max(sbest, sb_wave_max(mv));
+                    for (int k = C - 1; k >= 0; --k) kk = (h[k] == m) ? k : kk;
+                    const bool imp = m > lbest;                   // strictly: an earlier row of this lane wins a tie
+                    lk = imp ? kk : lk;
+                    lstep = imp ? u : lstep;
+                    lbest = max(lbest, m);
                 }
             });
         }
-        if (lbest > 0) {
-            const u64 key = ((u64)(u32)lbest << 40) | (SW_KEY_IDX_MASK - (u64)(u32)lidx);
-            kbest = key > kbest ? key : kbest;
+        {
+            const int r = lstep - lane, c = c0 + lk;
+            if (lbest > 0 && r >= 1 && r <= rows && c <= cols) {
+                const u64 key = ((u64)(u32)lbest << 40) | (SW_KEY_IDX_MASK - (u64)(u32)(r * M + c));
+                kbest = key > kbest ? key : kbest;
+            }
         }
     }
     // the pair's arg-max: highest score, lowest linear index among equals (serial_smithW.c:240-242)

@@ -67,6 +67,7 @@ struct BatchParams {
     int match, mismatch, ngap;       // plain scores (H-space), ngap = -gap
     int* bnd; int64_t bnd_pstride;   // boundary column between strips (only when cols > 64 * C), ints per pair
     sw_result* results;
+    int debug;                       // bit 0: drop the H / P stores (timing experiments only)
 };
 __global__ void sw_batch_codes(const unsigned char* b, int64_t rows, int64_t b_pstride, unsigned char* bcode, int64_t per, int front,
                                const unsigned int* present, unsigned char* atab);

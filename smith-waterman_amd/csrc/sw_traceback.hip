@@ -58,16 +58,13 @@ __device__ __forceinline__ int tb_walk(int& ti, int& tj, int& status, u32& rec) 
         "s_mov_b32 %[st], 0\n\t"
         "v_mov_b32 v63, 0\n"
         "Ltb_loop_%=:\n\t"
-        "s_set_gpr_idx_on %[ti], 0x1\n\t"          /* src0 of the next VALU ops is v[64 + ti] */
-        "s_nop 0\n\t"
+        "s_set_gpr_idx_on %[ti], 0x1\n\t"          /* src0 of the next VALU op is v[64 + ti] */
         "v_mov_b32 v62, v64\n\t"
         "s_set_gpr_idx_off\n\t"
-        "s_nop 0\n\t"
+        "s_mov_b32 m0, %[k]\n\t"                   /* (also the wait state between the VALU write of v62 and v_readlane) */
         "v_readlane_b32 %[c], v62, %[tj]\n\t"
-        "s_nop 3\n\t"
         "s_cmp_lt_i32 %[c], 1\n\t"
         "s_cbranch_scc1 Ltb_end_%=\n\t"
-        "s_mov_b32 m0, %[k]\n\t"
         "v_writelane_b32 v63, %[c], m0\n\t"
         "s_add_u32 %[k], %[k], 1\n\t"
         "s_and_b32 %[t], %[c], 1\n\t"
@@ -108,23 +105,63 @@ __device__ __forceinline__ u32 tb_wave_prefix_sum(u32 v) {   // inclusive, 64 la
 // (>= 0) or res[k].max_pos, negates the path, writes its length to res[k].path_len, optionally the visited indices to
 // paths + k * cap and the index of the cell the walk stopped at (the first cell with P <= 0) to stop[k].
 template <typename PT>
-__global__ void __launch_bounds__(64) sw_traceback_wave(PT* __restrict__ P, int64_t M, int64_t rows1, int64_t pstride, int64_t start_pos,
-                                                        int64_t* __restrict__ paths, int64_t cap, sw_result* __restrict__ res, int64_t* __restrict__ stop) {
-    const int lane = threadIdx.x;
+__global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int64_t M, int64_t rows1, int64_t pstride, int64_t start_pos,
+                                                         int64_t* __restrict__ paths, int64_t cap, sw_result* __restrict__ res, int64_t* __restrict__ stop) {
+    // cursor of the walking wave (row, column, done) for the second wave of a two-wave launch, which reads the cells the walk is
+    // heading for -- the band around the diagonal above the cursor -- ahead of it, so that the window loads hit the L2 instead
+    // of paying an HBM miss per window (a freshly filled 1 GB matrix is nowhere near any cache).  Results do not depend on it.
+    __shared__ volatile int64_t cur[3];
+    const int lane = threadIdx.x & 63;
     const int64_t k = blockIdx.x;
     if (res[k].path_len < 0) return;            // the fill of this problem was aborted
     PT* Pk = P + k * pstride;
-    int64_t* path = paths ? paths + k * cap : nullptr;
     const int64_t pos_l = start_pos >= 0 ? start_pos : res[k].max_pos;
     const int64_t pos = ((int64_t)__builtin_amdgcn_readfirstlane((int)(pos_l >> 32)) << 32) | (int64_t)(u32)__builtin_amdgcn_readfirstlane((int)(u32)pos_l);
-    int64_t gi = pos / M, gj = pos - gi * M, len = 0;
     const int64_t total = rows1 * M;
+    const bool warm = blockDim.x > 64;
+    if (warm) {
+        if (threadIdx.x == 0) { cur[0] = pos / M; cur[1] = pos - (pos / M) * M; cur[2] = 0; }
+        __syncthreads();
+        if (threadIdx.x >= 64) {
+            constexpr int LINE = 128 / (int)sizeof(PT);            // matrix columns per 128-byte line
+            int64_t next_row = cur[0];                               // rows above this one are still to be touched
+            u32 sink = 0;
+            for (;;) {
+                const int64_t gi = cur[0], gj = cur[1];
+                if (cur[2]) break;
+                const int64_t upto = gi - 640 > 0 ? gi - 640 : 0;    // stay ~600 rows ahead of the walk
+                if (next_row > gi) next_row = gi;
+                int batches = 0;
+                while (next_row > upto && batches < 4) {             // 64 rows per pass, lane l takes row next_row - l
+                    const int64_t r = next_row - lane;
+                    const int64_t pc = gj - (gi - r);                // where a pure diagonal from the cursor crosses row r
+                    if (r >= 0) {
+#pragma unroll
+                        for (int q = -3; q < 3; ++q) {               // [pc - 3 LINE, pc + 3 LINE): 6 lines around it
+                            int64_t c = pc + (int64_t)q * LINE;
+                            c = c < 0 ? 0 : c;
+                            const int64_t idx = r * M + c;
+                            if (idx < total) sink += (u32)__hip_atomic_load((const unsigned char*)(Pk + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2-served, fills the L2
+                        }
+                    }
+                    next_row -= 64;
+                    ++batches;
+                }
+                if (batches == 0) __builtin_amdgcn_s_sleep(32);
+            }
+            if (sink == 0x9e3779b9u && stop == (int64_t*)1) stop[0] = 0;   // (keeps the loads alive; never true)
+            return;
+        }
+    }
+    int64_t* path = paths ? paths + k * cap : nullptr;
+    int64_t gi = pos / M, gj = pos - gi * M, len = 0;
     for (;;) {
         // window: rows r0 .. r0+63, columns c0 .. c0+63, the cursor in its bottom-right part
         const int64_t r0 = gi > 63 ? gi - 63 : 0, c0 = gj > 63 ? gj - 63 : 0;
         int ti = __builtin_amdgcn_readfirstlane((int)(gi - r0)), tj = __builtin_amdgcn_readfirstlane((int)(gj - c0));
         const int64_t w0 = r0 * M + c0;
         const uint64_t remain = (uint64_t)(total - w0) * sizeof(PT);
+        if (warm && lane == 0) { cur[0] = gi; cur[1] = gj; }
         tb_load_window<PT>(Pk + w0, (u32)__builtin_amdgcn_readfirstlane((int)(remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)remain)),
                            (u32)__builtin_amdgcn_readfirstlane((int)(u32)(M * (int64_t)sizeof(PT))), lane);
         int status = 0;
@@ -147,6 +184,7 @@ __global__ void __launch_bounds__(64) sw_traceback_wave(PT* __restrict__ P, int6
         gi = r0 + ti; gj = c0 + tj;
         if (status == 2 || gi < 0 || gj < 0) break;
     }
+    if (warm && lane == 0) cur[2] = 1;
     if (lane == 0) {
         res[k].path_len = len;
         if (stop) stop[k] = gi * M + gj;
