@@ -91,6 +91,34 @@ __device__ __forceinline__ int tb_walk(int& ti, int& tj, int& status, u32& rec) 
     return k;
 }
 
+// The same walk unrolled over the rows (scripts/gen_traceback_rows.py): it starts at row 63 of the window, so it serves every
+// window that is not clamped at the top of the matrix.  tj: column (lane) in, column of the next cursor / the stop cell out.
+// Returns `low`, the lowest row visited, and per row q >= low in lane q of `rec`: 4 * (LEFT steps in the row) + the code the row
+// was left with (3 DIAGONAL, 1 UP; in row `low` also 2 = through the left edge of the window, 0 = the path ended).
+// status: 1 -> next cursor (low - 1, tj), 3 -> next cursor (low, -1), 2 -> the path ended at (low, tj).
+__device__ __forceinline__ int tb_walk_rows(int& tj, int& status, u32& rec) {
+    int c, cnt, low;
+    asm volatile(
+        "v_mov_b32 v63, 3\n\t"
+        "s_mov_b32 %[cnt], 0\n\t"
+        "s_nop 0\n\t"
+#include "sw_traceback_rows.inc"
+        "v_mov_b32 %[rec], v63\n\t"
+        : [c] "=&s"(c), [cnt] "=&s"(cnt), [low] "=&s"(low), [st] "=&s"(status), [tj] "+s"(tj), [rec] "=v"(rec)
+        :
+        : "memory", "scc", "v63", TB_WINDOW_REGS);
+    return low;
+}
+
+__device__ __forceinline__ u32 tb_wave_max_u32(u32 v) {   // maximum over the 64 lanes, valid in lane 63
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true));
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ u32 tb_wave_prefix_sum(u32 v) {   // inclusive, 64 lanes
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
@@ -155,6 +183,12 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
     }
     int64_t* path = paths ? paths + k * cap : nullptr;
     int64_t gi = pos / M, gj = pos - gi * M, len = 0;
+#ifdef TB_PROFILE
+    uint64_t t_load = 0, t_walk = 0, t_flush = 0, nwin = 0, tA, tB;
+#define TB_T(x) x = __builtin_amdgcn_s_memrealtime()
+#else
+#define TB_T(x)
+#endif
     for (;;) {
         // window: rows r0 .. r0+63, columns c0 .. c0+63, the cursor in its bottom-right part
         const int64_t r0 = gi > 63 ? gi - 63 : 0, c0 = gj > 63 ? gj - 63 : 0;
@@ -162,13 +196,56 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
         const int64_t w0 = r0 * M + c0;
         const uint64_t remain = (uint64_t)(total - w0) * sizeof(PT);
         if (warm && lane == 0) { cur[0] = gi; cur[1] = gj; }
+        TB_T(tA);
         tb_load_window<PT>(Pk + w0, (u32)__builtin_amdgcn_readfirstlane((int)(remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)remain)),
                            (u32)__builtin_amdgcn_readfirstlane((int)(u32)(M * (int64_t)sizeof(PT))), lane);
         int status = 0;
+#ifdef TB_PROFILE
+        TB_T(tB); t_load += tB - tA; ++nwin;
+#endif
+        if (ti == 63) {
+            // the row-unrolled walk: one record per ROW
+            const int sj = tj;
+            u32 rec;
+            TB_T(tA);
+            const int low = tb_walk_rows(tj, status, rec);
+#ifdef TB_PROFILE
+            TB_T(tB); t_walk += tB - tA;
+#endif
+            const bool vis = lane >= low;
+            const u32 cnt = vis ? rec >> 2 : 0u, code = rec & 3u;
+            const u32 ncell = vis ? cnt + ((code & 1u) ? 1u : 0u) : 0u;           // cells of my row on the path
+            const u32 cmove = vis ? cnt + (code == 3u ? 1u : 0u) : 0u;            // columns the path moves left in my row
+            const u32 d = (cmove << 16) | ncell;
+            const u32 incl = tb_wave_prefix_sum(d);
+            const u32 tot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+            const u32 above = tot - incl;                                          // rows walked before mine: lanes > mine
+            const int64_t ecol = c0 + sj - (int64_t)(above >> 16);                 // column at which the walk enters my row
+            const int64_t rbase = (r0 + lane) * M;
+            const int64_t poff = len + (int64_t)(above & 0xffffu);
+            const int maxc = __builtin_amdgcn_readfirstlane((int)tb_wave_max_u32(ncell));
+            for (int i = 0; i < maxc; ++i) {
+                if ((u32)i < ncell) {
+                    const int64_t idx = rbase + ecol - i;
+                    Pk[idx] = (PT)((u32)i < cnt ? -SW_LEFT : -(int)code);
+                    if (path && poff + i < cap) path[poff + i] = idx;
+                }
+            }
+            len += (int64_t)(tot & 0xffffu);
+            ti = status == 1 ? low - 1 : low;
+            if (status == 3) { tj = -1; status = 1; }
+#ifdef TB_PROFILE
+            TB_T(tA); t_flush += tA - tB;
+#endif
+        } else
         do {
             const int si = ti, sj = tj;            // cursor at the start of this run of steps
             u32 rec;
+            TB_T(tA);
             const int n = tb_walk(ti, tj, status, rec);
+#ifdef TB_PROFILE
+            TB_T(tB); t_walk += tB - tA;
+#endif
             if (n > 0) {
                 const u32 c = lane < n ? rec : 0u;
                 const u32 d = ((c & 1u) << 16) | (c >> 1);          // (rows up, columns left) of this step
@@ -180,6 +257,9 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
                 }
                 len += n;
             }
+#ifdef TB_PROFILE
+            TB_T(tA); t_flush += tA - tB;
+#endif
         } while (status == 0);
         gi = r0 + ti; gj = c0 + tj;
         if (status == 2 || gi < 0 || gj < 0) break;
@@ -188,6 +268,9 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
     if (lane == 0) {
         res[k].path_len = len;
         if (stop) stop[k] = gi * M + gj;
+#ifdef TB_PROFILE
+        if (stop) { stop[1] = (int64_t)t_load; stop[2] = (int64_t)t_walk; stop[3] = (int64_t)t_flush; stop[4] = (int64_t)nwin; }   // 100 MHz ticks
+#endif
     }
 }
 template __global__ void sw_traceback_wave<int32_t>(int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*, int64_t*);
