@@ -492,6 +492,20 @@ class MultiFill:
             out.append((dev.value, lo.value, hi.value, H, P.astype(np.int32)))
         return out
 
+    def band_tensors(self):
+        """[(device, lo, hi, H, P)] as torch tensors that alias the band-local device matrices (no copy; H None when not kept).
+        Row 0 of a band is its halo row (= row lo of the whole matrix)."""
+        import torch
+        out = []
+        for g in range(lib().sw_multi_nbands(self._h)):
+            dev, lo, hi, dH, dP = _i32(), _i64(), _i64(), _vp(), _vp()
+            _check(lib().sw_multi_band_info(self._h, g, ctypes.byref(dev), ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(dH), ctypes.byref(dP)))
+            shape = (hi.value - lo.value + 1, self.cols + 1)
+            H = torch.as_tensor(_RawDevice(dH.value, shape, "<i4", self), device=f"cuda:{dev.value}") if self.want_h else None
+            P = torch.as_tensor(_RawDevice(dP.value, shape, "|i1" if self.pbytes == 1 else "<i4", self), device=f"cuda:{dev.value}")
+            out.append((dev.value, lo.value, hi.value, H, P))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             lib().sw_multi_free(self._h)

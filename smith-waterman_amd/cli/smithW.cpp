@@ -119,6 +119,14 @@ int main(int argc, char** argv) {
     } else if (builtin) { memcpy(b.data(), "GGTTGACTA", 9); memcpy(a.data(), "TGTTACGG", 8); }
     else CHECK(sw_generate(cols, rows, seed, a.data(), b.data()));
     if (dump) { if (builtin) printf("\n Using built-in data for testing .."); printf("\nMatrix[%lld][%lld]\n", rows, cols); }
+    else {
+        // the lines omp_smithW-v1-refinedOrig.cpp:119,138-142 print (there both matrices and both sequences are ints; here the
+        // footprint is what is resident in HBM: H int32 | int64, P int32 | int8, one byte per letter)
+        printf("Problem size: Matrix[%lld][%lld]\n", n, m);
+        const unsigned long long sz = ((unsigned long long)(m + n) + (unsigned long long)m * n * ((h64 ? 8 : 4) + (p8 && !devices.empty() ? 1 : 4))) / 1024 / 1024;
+        if (sz >= 1024) printf("Total memory footprint is:%llu GB\n", sz / 1024);
+        else printf("Total memory footprint is:%llu MB\n", sz);
+    }
 
     if (!devices.empty()) {
         // ---- one matrix over several GPUs: row bands, one band-resident launch per GPU, halo rows relayed over xGMI ----

@@ -194,6 +194,7 @@ struct FillJob {
     int reserve_cus = 0;          // CUs left free for other kernels (halo transfers)
     bool concurrent = false;      // do not order this launch behind fills on other streams (the caller partitions the CUs)
     int64_t total_rows = 0;       // band: rows of the whole matrix (bounds the scores a halo can carry)
+    bool reserve_only = false;    // size the per-context workspaces for this job and return: nothing is launched
 };
 
 // called with g_dev[device].mu held: make `stream` wait for the fill enqueued last on another stream of this device.  The
@@ -319,6 +320,10 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             }
             p.edge4 = c->d_edge4; p.e4stride = e4stride; p.edge4_pstride = (int64_t)S * e4stride;
             p.gbias = (c->epoch8 << 24) | 0x10000u;
+        }
+        if (j.reserve_only) {   // every workspace of this job exists now (and is wiped where fresh): wait for that, launch nothing
+            HIP_TRY(hipStreamSynchronize(stream));
+            return SW_OK;
         }
         HIP_TRY(hipMemsetAsync(c->d_alpha, 0, 32, stream));
         {
@@ -583,6 +588,24 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
     c->last_batch_kernel = 1;
     c->last_grid = (chunk + 3) / 4; c->last_strips = nstrips;
     return SW_OK;
+}
+
+// (library-internal) Sizes ctx's workspaces for band-resident launches of this shape without launching anything.  sw_multi_create
+// calls it for every band: a launch that has to allocate synchronises its stream, and with several persistent band kernels on
+// one GPU that stream can share a hardware queue with a kernel that is still polling for its halo -- which only arrives once the
+// host is past the launches (seen with 8 bands on one GPU: band 1 gave up after "band_wait_ms" and the relay stalled).
+int sw_fill_band_reserve(sw_ctx* c, int64_t cols, int64_t rows, int64_t total_rows, const sw_scores* scores, int h_elem_bytes, int p_elem_bytes, int want_h,
+                         void* stream_) {
+    const sw_scores* sc = scores ? scores : &kDefaultScores;
+    if (!c || cols <= 0 || rows <= 0) { set_err("sw_fill_band_reserve: bad argument"); return SW_EINVAL; }
+    if (int rc = check_dims(cols, rows, sc, cols, total_rows)) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    FillJob j = make_job((const char*)16, cols, (const char*)16, rows, want_h ? (void*)16 : nullptr, h_elem_bytes, (void*)16, p_elem_bytes, cols + 1, nullptr, nullptr, nullptr);
+    j.d_top_gran = (const unsigned long long*)16; j.d_bot_gran = (unsigned long long*)16;   // (placeholders: only their presence matters)
+    j.top_tag = j.bot_tag = 1; j.total_rows = total_rows; j.concurrent = true; j.reserve_only = true;
+    j.d_keys = c->d_key;
+    std::unique_lock<std::mutex> lk(g_dev[c->device & 63].mu);
+    return launch_fill(c, sc, j, (hipStream_t)stream_);
 }
 
 // BASELINE config 5: npairs independent cols x rows problems; pair k reads a at d_a + k*a_stride, b at d_b + k*b_stride.

@@ -59,6 +59,8 @@ extern "C" {
 
 int sw_traceback_stop_device(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos, sw_result* d_result, int64_t* d_stop,
                              void* stream);   // sw_api.hip (library-internal)
+int sw_fill_band_reserve(sw_ctx* c, int64_t cols, int64_t rows, int64_t total_rows, const sw_scores* scores, int h_elem_bytes, int p_elem_bytes, int want_h,
+                         void* stream);       // sw_api.hip (library-internal)
 
 void sw_multi_free(sw_multi* m) {
     if (!m) return;
@@ -145,6 +147,8 @@ int sw_multi_create(const int* devices, int ndev, const char* a, int64_t cols, c
             (bd.d_bot && !bd.host_gran && hipMemset(bd.d_bot, 0, (size_t)(cols + 1) * 8) != hipSuccess)) {
             set_err("sw_multi_create: device setup failed"); rc = SW_EDEVICE; break;
         }
+        // every workspace a band launch needs exists before the first fill: no launch call may have to synchronise later
+        if ((rc = sw_fill_band_reserve(bd.ctx, cols, br, rows, nullptr, 4, p_elem_bytes, want_h, bd.stream)) != SW_OK) break;
         // bands that share a GPU split its CUs (every workgroup of a launch must be resident)
         int share = 0;
         for (int k = 0; k < nb; ++k) share += (m->bands[k].device == bd.device);
@@ -232,7 +236,12 @@ int sw_multi_fill(sw_multi* m, const sw_scores* scores, int nchunks, sw_result* 
             if (next[g] < S) busy = true;
         }
         if (moved) deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
-        else if (busy && std::chrono::steady_clock::now() > deadline) { set_err("sw_multi_fill: the band pipeline stalled"); return give_up(SW_ETIMEOUT); }
+        else if (busy && std::chrono::steady_clock::now() > deadline) {
+            char msg[512]; int n = snprintf(msg, sizeof msg, "sw_multi_fill: the band pipeline stalled; strips forwarded per band:");
+            for (int g = 0; g + 1 < nb && n < (int)sizeof msg - 32; ++g) n += snprintf(msg + n, sizeof msg - n, " %lld/%lld", (long long)next[g], (long long)S);
+            set_err("%s", msg);
+            return give_up(SW_ETIMEOUT);
+        }
     }
     if (getenv("SW_MULTI_DEBUG")) {
         fprintf(stderr, "sw_multi_fill: relay done after %.3f s;", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
