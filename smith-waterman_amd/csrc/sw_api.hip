@@ -67,6 +67,7 @@ struct sw_ctx {
     int64_t last_batch_kernel = 0;      // 1: the last sw_batch_device call ran on sw_batch_wave (one pair per wave)
     int64_t last_grid = 0, last_strips = 0;
     int64_t last_strips2 = 0;           // strips of the two-column kernel in the last launch (0: not launched)
+    int64_t last_scouts = 0;            // scout workgroups of that launch
     std::map<void*, void*> out_base;    // sw_alloc_outputs: pointer handed out -> allocation to free
 };
 
@@ -151,6 +152,7 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "last_grid")) return c->last_grid;
     if (!strcmp(name, "last_strips")) return c->last_strips;
     if (!strcmp(name, "last_strips2")) return c->last_strips2;
+    if (!strcmp(name, "last_scouts")) return c->last_scouts;
     if (!strcmp(name, "last_batch_kernel")) return c->last_batch_kernel;
     return -1;
 }
@@ -355,7 +357,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         }
         const unsigned char* cbp = c->d_cb;
         bool launched = false;
-        c->last_strips2 = 0;
+        c->last_strips2 = 0; c->last_scouts = 0;
         // Two matrix columns per lane (sw_systolic2.inc): half as many strips -- and row segments of 504 bytes per store -- for the
         // same work: 16384^2 +4 %, 8192^2 +11 %, 24576^2 +29 %, 32768^2 +32 %, 65536^2 +9 % over one column per lane.  Whole
         // matrix of one pair, int32 H and P both stored, rows a multiple of 16; the alphabet (found on the device) must allow the
@@ -380,7 +382,20 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             int per_cu = 0;
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, swk::sw_systolic2<6>, 768, 0));
             if (per_cu >= 1) {
-                const int grid2 = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S2, maxb), (int64_t)per_cu * c->num_cus));
+                int grid2 = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S2, maxb), (int64_t)per_cu * c->num_cus));
+                // Scouts (sw_systolic2.inc): while every strip has a workgroup of its own and half as many more fit the device, the chain
+                // of strips runs in extra workgroups that keep nothing but the edge columns, and the workgroups that write the matrices
+                // follow them instead of each other.  (debug bit 17: off)
+                // One scout strip per workgroup where the device has the workgroups for it (S2 fillers + S2 scouts), two in as many
+                // scout workgroups as it takes to fit; at least 1.5 S2 workgroups in all.
+                const int64_t avail = std::min<int64_t>(maxb, (int64_t)per_cu * c->num_cus);
+                const int64_t ndouble = std::max<int64_t>(0, 2 * S2 - 1 - avail);   // (the last strip needs no scout: nobody reads its edge)
+                const int64_t nsc = S2 - 1 - ndouble;
+                const bool scouts = S2 >= 4 && 2 * ndouble <= S2 - 1 && nsc >= 1 && !(c->opt_debug & 131072);
+                p2.nscout = scouts ? (int)nsc : 0;
+                p2.scout_double = scouts ? (int)ndouble : 0;
+                if (scouts) grid2 = (int)(S2 + nsc);
+                c->last_scouts = p2.nscout;
                 // row 0 and column 0 are not the kernel's: zeros, except a band's halo row (its H comes from the row above, written by
                 // the kernel; its P belongs to the band above)
                 const bool has_top = j.d_top || j.d_top_gran;

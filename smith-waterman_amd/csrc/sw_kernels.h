@@ -53,6 +53,8 @@ struct FillParams {
     unsigned int gbias;                  // 0 = perm path not eligible on the host side (score range)
     int skip_if_perm;                    // sw_systolic: leave when the perm path applies (sw_systolic2 was launched for that case)
     int h_bytes;                         // sw_systolic2: bytes per H element (4 or 8); sw_systolic carries it as a template parameter
+    int scout_double;                    // sw_systolic2: the first scout_double scout workgroups carry two strips, the others one
+    int nscout;                          // sw_systolic2: workgroups 0..nscout-1 only run the chain (two strips each) and leave the edge columns to the others
 };
 constexpr int SW_PERM_PAD = -100;        // score of any cell outside the sequences (perm producer)
 
