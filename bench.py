@@ -122,7 +122,7 @@ def chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows):
     for a neighbour) and the lag per strip hand-off, for the dependency bound N^2 / ((2N-1) tau)."""
     import numpy as np
     S = (cols + 62) // 63
-    dbg = torch.zeros(6 * S + 64, dtype=torch.int64, device=out.res.device)
+    dbg = torch.zeros(16 * S + 256, dtype=torch.int64, device=out.res.device)
     eng.set_option("debug_buf", dbg.data_ptr())
     eng.fill_into(out, d_a, d_b)
     eng.synchronize()
@@ -131,21 +131,32 @@ def chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows):
     if S2 > 0:
         S = S2
     raw = dbg.cpu().numpy()
-    t = raw[:2 * S].reshape(S, 2).astype(np.float64) * 10.0   # 100 MHz ticks -> ns
+    nsc = int(eng.get_option("last_scouts")) if S2 > 0 else 0
+    # with scouts (sw_systolic2.inc) the chain of strips is theirs: their stamps sit at [0, 2 (S-1)) -- the last strip has no scout --
+    # and those of the workgroups that write the matrices ("fillers") at offset 6 S + 32
+    NS = S - 1 if nsc else S
+    t = raw[:2 * NS].reshape(NS, 2).astype(np.float64) * 10.0   # 100 MHz ticks -> ns
     steps = rows + 63 + (S - 1)
     tau = (t[0, 1] - t[0, 0]) / max(1, steps)
-    lag = float(np.diff(t[:, 1]).mean()) if S > 1 else 0.0
+    lag = float(np.diff(t[:, 1]).mean()) if NS > 1 else 0.0
     # shader clock while the kernel ran: s_memtime ticks per s_memrealtime tick (100 MHz), stamped around strip 0's producer
     ghz = None
     if S2 > 0 and raw[6 * S + 17] > raw[6 * S + 16] and t[0, 1] > t[0, 0]:
         ghz = float(raw[6 * S + 17] - raw[6 * S + 16]) / (t[0, 1] - t[0, 0])
-    return tau, lag, ghz
+    extra = {"scout_workgroups": nsc}
+    if nsc:
+        f = raw[6 * S + 32: 6 * S + 32 + 2 * S].reshape(S, 2).astype(np.float64) * 10.0
+        extra["filler_step_ns"] = float(np.median((f[:, 1] - f[:, 0]) / max(1, steps)))
+        extra["last_filler_after_last_scout_us"] = float((f[:, 1].max() - t[:, 1].max()) / 1e3)
+        extra["chain_end_to_end_us"] = float((t[:, 1].max() - t[0, 0]) / 1e3)
+    return tau, lag, ghz, extra
 
 
 def traffic_for(workload_key, kernel=None):
     """HBM bytes per launch from the committed PMC passes (scripts/gpu_pmc.sh), if they were taken on the kernel that ran."""
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))).get(workload_key, {})
+        f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        pm = json.load(open(f if os.path.exists(f) else os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))).get(workload_key, {})
         if kernel and pm.get("kernel") and pm["kernel"] != kernel:
             return None
         return pm.get("traffic_bytes_per_launch")
@@ -211,7 +222,7 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
         out, placement_ms = eng.alloc_outputs(d_a, d_b, cols, rows, h_dtype, p_dtype, trials=args.placement_trials)
     dt, kern_ms = timed(out, args.steps, args.warmup)
     res = out.result()
-    tau_ns, lag_ns, shader_ghz = chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows) if args.engine == 0 else (0.0, 0.0, None)
+    tau_ns, lag_ns, shader_ghz, chain_extra = chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows) if args.engine == 0 else (0.0, 0.0, None, {})
     clocks1 = _clocks()
     if world > 1:
         tmax = torch.tensor([dt], device=f"cuda:{local}")
@@ -242,7 +253,7 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
                      "traffic": traffic_for(key, "sw_systolic2" if int(eng.get_option("last_strips2")) > 0 else "sw_systolic") if args.engine == 0 else None,
                      "kernel": ("sw_systolic2" if int(eng.get_option("last_strips2")) > 0 else "sw_systolic") if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
                      "algorithmic_bytes_per_cell": bytes_per_cell, "measured_contiguous_fill_GBs": fill_gbs,
-                     "tau_step_ns": tau_ns, "strip_handoff_lag_ns": lag_ns,
+                     "tau_step_ns": tau_ns, "strip_handoff_lag_ns": lag_ns, **chain_extra,
                      # the chain of sequential steps with free hand-offs: rows + columns / (columns per lane) steps of tau each
                      "dependency_bound_gcups": (cells / ((rows + cols / (2 if int(eng.get_option("last_strips2")) > 0 else 1) - 1) * tau_ns)) if tau_ns > 0 else None},
     }
