@@ -174,7 +174,7 @@ class Fill:
     def result(self):
         r = self.res.cpu().tolist()
         if r[2] < 0:
-            raise SwError(-62, "in-kernel hand-off wait timed out")
+            raise SwError(-62, f"in-kernel hand-off wait timed out (code {-r[2]})")
         return {"max_pos": r[0], "max_score": r[1], "path_len": r[2]}
 
 

@@ -48,7 +48,8 @@ struct sw_ctx {
     unsigned int* d_edge4 = nullptr;    // perm producer: lane-63 columns as self-tagged 4-byte values
     size_t edge4_cap = 0;               // elements
     unsigned epoch8 = 0;                // 8-bit launch tag of those values
-    unsigned char* d_alpha = nullptr;   // [0..31] presence map of byte values, [64..323] letter code table + letter count
+    unsigned char* d_alpha = nullptr;   // [64..323] letter code table + letter count
+    unsigned int* d_part = nullptr;     // sw_prep_scan: one 256-bit presence map of byte values per block (up to 2048 blocks)
     int64_t opt_debug = 0;
     int64_t opt_store_policy = 0;       // systolic H/P stores: 0 auto (by size), 1 write-back, 2 streaming (nt)
     int64_t opt_xcd_order = 0;          // systolic: 1 = neighbouring strip groups on one XCD
@@ -88,6 +89,7 @@ int sw_create(int device, sw_ctx** out) {
     HIP_TRY(hipMemset(c->d_key, 0, 64));
     HIP_TRY(hipMalloc((void**)&c->d_alpha, 512));
     HIP_TRY(hipMemset(c->d_alpha, 0, 512));
+    HIP_TRY(hipMalloc((void**)&c->d_part, 2048 * 32));
     *out = c;
     return SW_OK;
 }
@@ -100,6 +102,7 @@ void sw_destroy(sw_ctx* c) {
     if (c->d_cb) (void)hipFree(c->d_cb);
     if (c->d_edge4) (void)hipFree(c->d_edge4);
     if (c->d_alpha) (void)hipFree(c->d_alpha);
+    if (c->d_part) (void)hipFree(c->d_part);
     if (c->d_keys) (void)hipFree(c->d_keys);
     if (c->d_bcodes) (void)hipFree(c->d_bcodes);
     if (c->d_bnd) (void)hipFree(c->d_bnd);
@@ -197,6 +200,7 @@ struct FillJob {
     bool concurrent = false;      // do not order this launch behind fills on other streams (the caller partitions the CUs)
     int64_t total_rows = 0;       // band: rows of the whole matrix (bounds the scores a halo can carry)
     bool reserve_only = false;    // size the per-context workspaces for this job and return: nothing is launched
+    bool zero_key = false;        // the preparation kernel also zeroes d_keys[0..1] (fill_one leaves that to it)
 };
 
 // called with g_dev[device].mu held: make `stream` wait for the fill enqueued last on another stream of this device.  The
@@ -327,21 +331,27 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             HIP_TRY(hipStreamSynchronize(stream));
             return SW_OK;
         }
-        HIP_TRY(hipMemsetAsync(c->d_alpha, 0, 32, stream));
-        {
+        // input preparation, two dispatches (sw_systolic.hip): presence maps of the letters, then codes / padded copies of b -- and, for
+        // the two-column kernel, row 0 and column 0 of the matrices and the arg-max key
+        bool prepped = false;
+        auto prepare = [&](void* zH, void* zP, bool skip_row0) {
             const int64_t total = (cols + rows) * j.npairs;
-            const unsigned nblk = (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 4095) / 4096, 1024));
-            hipLaunchKernelGGL(swk::sw_alpha_scan, dim3(nblk), dim3(256), 0, stream, ua, cols, j.a_pstride, ub, rows, j.b_pstride, j.npairs,
-                               (unsigned int*)c->d_alpha);
-        }
-        hipLaunchKernelGGL(swk::sw_pad_b, dim3((unsigned)((per + 255) / 256), (unsigned)j.npairs), dim3(256), 0, stream, ub, rows, bfront,
-                           j.b_pstride, c->d_cb, d_cb16, d_cbc, (const unsigned int*)c->d_alpha, c->d_alpha + 64, per);
+            const unsigned nscan = (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 1023) / 1024, 2048));
+            hipLaunchKernelGGL(swk::sw_prep_scan, dim3(nscan), dim3(256), 0, stream, ua, cols, j.a_pstride, ub, rows, j.b_pstride, j.npairs, c->d_part);
+            const unsigned npad = (unsigned)((per + 255) / 256);
+            const unsigned nzero = (zH || zP) ? (unsigned)((cols + 1 + rows + 255) / 256) : 0u;
+            hipLaunchKernelGGL(swk::sw_prep_code, dim3(npad + nzero, (unsigned)j.npairs), dim3(256), 0, stream, ub, rows, bfront, j.b_pstride, c->d_cb, d_cb16,
+                               d_cbc, (const unsigned int*)c->d_part, (int)nscan, c->d_alpha + 64, per, (int)npad, zH, j.h_elem_bytes, zP, j.p_elem_bytes,
+                               cols + 1, rows + 1, skip_row0 ? 1 : 0, j.zero_key ? j.d_keys : nullptr);
+            prepped = true;
+        };
         p.bcode = d_cbc;
         p.atab = c->d_alpha + 64;
         const bool fast = (j.d_top == nullptr) && (j.d_top_gran == nullptr) && (sc->mismatch <= 0) && !(c->opt_debug & 4);
         p.phi_base = fast ? (int)S - 1 : -1;
         p.bfront = (int)bfront;
         p.bpad16 = d_cb16;
+        p.bpad8 = c->d_cb;
         p.bpad_pstride = per;
         const int64_t ngroups = ((S + NS - 1) / NS) * j.npairs;
         const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : std::max<int64_t>(8, (int64_t)c->num_cus - j.reserve_cus);
@@ -371,7 +381,8 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         const double est_hbm = (double)(cols + 1) * (double)(rows + 1) * ((j.d_H ? (double)j.h_elem_bytes : 0.0) + (j.d_P ? (double)j.p_elem_bytes : 0.0)) / 3.2e12;
         const bool pays = (j.d_H && j.d_P && j.p_elem_bytes == 4) || (j.d_H && j.h_elem_bytes == 8) || est_chain >= (j.d_H ? 0.5 : 2.0) * est_hbm || (c->opt_debug & 32768);
         const bool two_cols = pays && perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 &&
-                              !j.d_left && !j.d_right && j.stride == cols + 1 && rows % 16 == 0 && rows >= 16 && cols >= 1 &&
+                              !j.d_left && !j.d_right && j.stride == cols + 1 && (rows % 16 == 0 || !j.d_bot_gran) && rows >= 1 && cols >= 1 &&   // (a band's last row leaves from a full block)
+                             
                               (base_mode || (cols % 2 == 0)) &&   // (an odd column count leaves one lane with a single column: only the base mode handles it)
                               !(c->opt_debug & (2 | 8 | 64 | 128 | 512 | 16384));
         if (two_cols) {
@@ -398,13 +409,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 c->last_scouts = p2.nscout;
                 // row 0 and column 0 are not the kernel's: zeros, except a band's halo row (its H comes from the row above, written by
                 // the kernel; its P belongs to the band above)
-                const bool has_top = j.d_top || j.d_top_gran;
-                if (!has_top) {
-                    if (j.d_H) HIP_TRY(hipMemsetAsync(j.d_H, 0, (size_t)(cols + 1) * (size_t)j.h_elem_bytes, stream));
-                    if (j.d_P) HIP_TRY(hipMemsetAsync(j.d_P, 0, (size_t)(cols + 1) * (size_t)j.p_elem_bytes, stream));
-                }
-                hipLaunchKernelGGL(swk::sw_zero_col0, dim3((unsigned)((rows + 1 + 255) / 256)), dim3(256), 0, stream, j.d_H, j.h_elem_bytes, j.d_P,
-                                   j.p_elem_bytes, cols + 1, rows + 1, has_top ? 1 : 0);
+                prepare(j.d_H, j.d_P, j.d_top || j.d_top_gran);
                 const int nc2 = c->opt_consumers == 0 ? (chain_bound ? 5 : 6) : (int)std::min<int64_t>(7, c->opt_consumers);   // + 9 - nc2 importers
                 if (nc2 == 7) hipLaunchKernelGGL(swk::sw_systolic2<7>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
                 else if (nc2 == 6) hipLaunchKernelGGL(swk::sw_systolic2<6>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
@@ -414,6 +419,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 c->last_strips2 = S2;
             }
         }
+        if (!prepped) prepare(nullptr, nullptr, false);
 #define SW_LAUNCH(ns, nc)                                                                                                        \
     if (!launched && NS == ns && NC == nc) {                                                                                      \
         launched = true;                                                                                                          \
@@ -463,8 +469,9 @@ static int fill_one(sw_ctx* c, const sw_scores* scores, FillJob j, int64_t gcols
     HIP_TRY(hipSetDevice(c->device));
     DevOrder order(c, stream, j.concurrent);
     if (order.rc) return order.rc;
-    HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream));
     j.d_keys = c->d_key;
+    j.zero_key = c->opt_engine == 0 && cols > 0 && rows > 0;   // (the systolic engine's preparation kernel zeroes the key and the abort flag)
+    if (!j.zero_key) HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream));
     if (cols == 0 || rows == 0) {
         // no interior cell: H (= halo row / zero column) and P are all boundary
         if (j.stride != cols + 1 || j.d_left || j.d_right || j.d_top_gran || j.d_bot_gran) { set_err("%s: empty tiles / bands are not supported", who); return SW_EINVAL; }
@@ -540,12 +547,9 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
     const unsigned char* ua = (const unsigned char*)d_a;
     const unsigned char* ub = (const unsigned char*)d_b;
     // alphabet of the whole batch -> letter codes; the count decides whether the profile look-up applies
-    HIP_TRY(hipMemsetAsync(c->d_alpha, 0, 32, stream));
-    {
-        const int64_t total = (cols + rows) * npairs;
-        const unsigned nblk = (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 4095) / 4096, 2048));
-        hipLaunchKernelGGL(swk::sw_alpha_scan, dim3(nblk), dim3(256), 0, stream, ua, cols, a_stride, ub, rows, b_stride, npairs, (unsigned int*)c->d_alpha);
-    }
+    const int64_t total_letters = (cols + rows) * npairs;
+    const unsigned nscan = (unsigned)std::max<int64_t>(1, std::min<int64_t>((total_letters + 4095) / 4096, 2048));
+    hipLaunchKernelGGL(swk::sw_prep_scan, dim3(nscan), dim3(256), 0, stream, ua, cols, a_stride, ub, rows, b_stride, npairs, c->d_part);
     const int front = 64;
     const int64_t per = ((rows + front + 80 + 72 + 15) / 16) * 16;   // (+40: the drain steps of the delayed int8 P stores read on)
     const int C = cols <= 256 ? 4 : cols <= 512 ? 8 : 16;
@@ -574,7 +578,7 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
     for (int64_t k0 = 0; k0 < npairs; k0 += chunk) {
         const int64_t n = std::min(chunk, npairs - k0);
         hipLaunchKernelGGL(swk::sw_batch_codes, dim3((unsigned)std::min<int64_t>((per + 255) / 256, 64), (unsigned)n), dim3(256), 0, stream, ub + k0 * b_stride, rows,
-                           b_stride, c->d_bcodes, per, front, (const unsigned int*)c->d_alpha, c->d_alpha + 64);
+                           b_stride, c->d_bcodes, per, front, (const unsigned int*)c->d_part, (int)nscan, c->d_alpha + 64);
         if (k0 == 0) {   // the letter count (4 bytes) decides the path: the one host round trip of a batch call
             unsigned int nletters = 0;
             HIP_TRY(hipMemcpyAsync(&nletters, c->d_alpha + 64 + 256, 4, hipMemcpyDeviceToHost, stream));

@@ -33,9 +33,16 @@ constexpr u32 SB_OOB = 0xFFFFFF00u;
 // bcode[pair * per + front + i] = code(b[i]); 0x0D outside the sequence -- as a v_perm_b32 selector byte that yields 0xFF, the
 // score -1 of a cell outside the matrix.  Block (0,0) publishes the code table (atab[0..255], letter count at atab[256]).
 __global__ void __launch_bounds__(256) sw_batch_codes(const unsigned char* __restrict__ b, int64_t rows, int64_t b_pstride, unsigned char* __restrict__ bcode,
-                                                      int64_t per, int front, const unsigned int* __restrict__ present, unsigned char* __restrict__ atab) {
+                                                      int64_t per, int front, const unsigned int* __restrict__ part, int npart, unsigned char* __restrict__ atab) {
     __shared__ unsigned char tab[256];
+    __shared__ unsigned int present[8];
     {
+        if (threadIdx.x < 8) {   // the batch's presence map: OR of the partial maps of sw_prep_scan
+            unsigned int m = 0;
+            for (int k = 0; k < npart; ++k) m |= part[k * 8 + threadIdx.x];
+            present[threadIdx.x] = m;
+        }
+        __syncthreads();
         const int t = threadIdx.x;
         int rank = 0, nletters = 0;
 #pragma unroll

@@ -29,6 +29,7 @@ struct FillParams {
     int phi_base;              // systolic: >= 0 -> fast producers, phi = phi_base - s; < 0 -> generic
     int bfront;                // systolic: index of b[0] inside bpad / bpad16
     const unsigned short* bpad16;
+    const unsigned char* bpad8;          // sw_systolic2: zero-padded byte copy of b, same layout as bpad16 (b[0] at index bfront)
     unsigned long long* dbg;   // optional: per strip {start, end} s_memrealtime stamps of its producer (experiments)
     int p_bytes;               // bytes per P element: 4 (reference layout) or 1 (compact, systolic engine only)
     int store_nt;              // systolic: streaming (nt) H/P stores
@@ -72,7 +73,7 @@ struct BatchParams {
     int debug;                       // bit 0: drop the H / P stores (timing experiments only)
 };
 __global__ void sw_batch_codes(const unsigned char* b, int64_t rows, int64_t b_pstride, unsigned char* bcode, int64_t per, int front,
-                               const unsigned int* present, unsigned char* atab);
+                               const unsigned int* part, int npart, unsigned char* atab);
 template <int C, int PB>
 __global__ void sw_batch_wave(BatchParams p);
 
@@ -83,11 +84,11 @@ __global__ void sw_systolic(const unsigned char* a, const unsigned char* b, cons
 __global__ void sw_wipe_u32(unsigned int* buf, size_t n);
 template <int NC>
 __global__ void sw_systolic2(const unsigned char* a, const unsigned char* b, FillParams p);
-__global__ void sw_zero_col0(void* H, int h_bytes, void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0);
-__global__ void sw_alpha_scan(const unsigned char* a, int64_t cols, int64_t a_pstride, const unsigned char* b, int64_t rows, int64_t b_pstride,
-                              int64_t npairs, unsigned int* present);
-__global__ void sw_pad_b(const unsigned char* b, int64_t rows, int64_t front, int64_t b_pstride, unsigned char* bpad, unsigned short* bpad16,
-                         unsigned char* bcode, const unsigned int* present, unsigned char* atab, int64_t per);
+__global__ void sw_prep_scan(const unsigned char* a, int64_t cols, int64_t a_pstride, const unsigned char* b, int64_t rows, int64_t b_pstride, int64_t npairs,
+                             unsigned int* part);
+__global__ void sw_prep_code(const unsigned char* b, int64_t rows, int64_t front, int64_t b_pstride, unsigned char* bpad, unsigned short* bpad16,
+                             unsigned char* bcode, const unsigned int* part, int npart, unsigned char* atab, int64_t per, int npad, void* H, int h_bytes,
+                             void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0, unsigned long long* key);
 __global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res, int n);
 template <typename PT>
 __global__ void sw_traceback_wave(PT* P, int64_t M, int64_t rows1, int64_t pstride, int64_t start_pos, int64_t* paths, int64_t cap, sw_result* res,

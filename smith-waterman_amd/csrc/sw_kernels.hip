@@ -268,7 +268,7 @@ __global__ void sw_finalize(const unsigned long long* key, const unsigned int* a
     const u64 k = key[i];
     res[i].max_score = (int64_t)(k >> 40);
     res[i].max_pos = k ? (int64_t)(SW_KEY_IDX_MASK - (k & SW_KEY_IDX_MASK)) : 0;
-    res[i].path_len = *abort_flag ? -1 : 0;
+    res[i].path_len = *abort_flag ? -(int64_t)*abort_flag : 0;   // (< 0: a hand-off wait gave up; the value says which kind)
 }
 
 // compact predecessor matrix -> the reference's int32 layout (same codes, sign-extended): 16 codes per thread and pass

@@ -82,13 +82,14 @@ __device__ __forceinline__ void lds_store(int* p, int v) {
 struct Spin {
     unsigned n = 0;
     uint64_t t0 = 0;
+    unsigned code = 1;        // what the abort flag is set to when this wait gives up (diagnostics: 2 consumer, 3 importer)
     __device__ __forceinline__ bool fail(unsigned int* abort_flag) {
         __builtin_amdgcn_s_sleep(1);
         if ((++n & 127u) != 0) return false;
         const uint64_t now = __builtin_amdgcn_s_memrealtime();  // 100 MHz
         if (t0 == 0) t0 = now;
         const bool expired = (now - t0) > 300000000ull;
-        if (expired) __hip_atomic_store((gu32*)abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (expired) __hip_atomic_store((gu32*)abort_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return expired || __builtin_amdgcn_readfirstlane((int)__hip_atomic_load((gu32*)abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0;
     }
 };
@@ -1788,10 +1789,13 @@ __global__ void __launch_bounds__(256) sw_wipe_u32(unsigned int* __restrict__ bu
         __hip_atomic_store((gu32*)(buf + i), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Which byte values occur in a and b (all pairs of a batch): 256-bit presence map, OR-ed into present[8].
-__global__ void __launch_bounds__(256) sw_alpha_scan(const unsigned char* __restrict__ a, int64_t cols, int64_t a_pstride,
-                                                     const unsigned char* __restrict__ b, int64_t rows, int64_t b_pstride, int64_t npairs,
-                                                     unsigned int* __restrict__ present) {
+// ---- input preparation: two small kernels per fill (they used to be seven dispatches: two memsets + scan + coding + two row-0
+// memsets + a column-0 kernel, 72 us of a 0.97 ms fill in round 2's trace) ---------------------------------------------------
+// sw_prep_scan: which byte values occur in a and b (all pairs of a batch).  Every block writes ITS 256-bit presence map to
+// part[block][8] -- no atomics, nothing to clear beforehand; the readers OR the `gridDim.x` maps together.
+__global__ void __launch_bounds__(256) sw_prep_scan(const unsigned char* __restrict__ a, int64_t cols, int64_t a_pstride,
+                                                    const unsigned char* __restrict__ b, int64_t rows, int64_t b_pstride, int64_t npairs,
+                                                    unsigned int* __restrict__ part) {
     __shared__ unsigned int seen[8];
     if (threadIdx.x < 8) seen[threadIdx.x] = 0;
     __syncthreads();
@@ -1806,36 +1810,64 @@ __global__ void __launch_bounds__(256) sw_alpha_scan(const unsigned char* __rest
 #pragma unroll
     for (int w = 0; w < 8; ++w) if (mine[w]) atomicOr(&seen[w], mine[w]);
     __syncthreads();
-    if (threadIdx.x < 8 && seen[threadIdx.x]) atomicOr(&present[threadIdx.x], seen[threadIdx.x]);
+    if (threadIdx.x < 8) part[blockIdx.x * 8 + threadIdx.x] = seen[threadIdx.x];
 }
 
-// bpad[front + i] = b[i] (bytes, zero padded) and bpad16[front + i] = b[i] (16-bit, padded with the
-// never-matching 0x100): producer lane l reads b[u-phi-l-1] for steps that reach phi+63 rows above and
-// ~200 rows below the matrix (those cells are never stored).  bcode: the same as letter codes (rank of the byte
-// value among the values present, 7 outside the sequence); block (0,0) also publishes the code table atab.
-__global__ void __launch_bounds__(256) sw_pad_b(const unsigned char* __restrict__ b, int64_t rows, int64_t front, int64_t b_pstride,
-                                                unsigned char* __restrict__ bpad, unsigned short* __restrict__ bpad16,
-                                                unsigned char* __restrict__ bcode, const unsigned int* __restrict__ present,
-                                                unsigned char* __restrict__ atab, int64_t per) {
-    __shared__ unsigned char tab[256];
-    {
-        const int t = threadIdx.x;   // rank of byte value t among the present values
-        int rank = 0, nletters = 0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            const unsigned int m = present[w];
-            nletters += __popc(m);
-            if (w < (t >> 5)) rank += __popc(m);
-            else if (w == (t >> 5)) rank += __popc(m & ((1u << (t & 31)) - 1u));
-        }
-        const bool here = (present[t >> 5] >> (t & 31)) & 1u;
-        tab[t] = (here && nletters <= 7) ? (unsigned char)rank : (unsigned char)7;
-        if (blockIdx.x == 0 && blockIdx.y == 0) {
-            atab[t] = tab[t];
-            if (t == 0) *(unsigned int*)(atab + 256) = (unsigned int)nletters;
-        }
+// the letter-code table from the partial presence maps: tab[v] = rank of byte value v among the values present (`maxcode` letters at
+// most, else `pad` for every value); returns the number of letters.  All 256 threads of the block take part.
+__device__ __forceinline__ int sw_code_table(const unsigned int* __restrict__ part, int npart, unsigned char* tab, int maxletters, unsigned char pad) {
+    __shared__ unsigned int present[8];
+    if (threadIdx.x < 8) {
+        unsigned int m = 0;
+        for (int k = 0; k < npart; ++k) m |= part[k * 8 + threadIdx.x];
+        present[threadIdx.x] = m;
     }
     __syncthreads();
+    const int t = threadIdx.x;
+    int rank = 0, nletters = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const unsigned int m = present[w];
+        nletters += __popc(m);
+        if (w < (t >> 5)) rank += __popc(m);
+        else if (w == (t >> 5)) rank += __popc(m & ((1u << (t & 31)) - 1u));
+    }
+    const bool here = (present[t >> 5] >> (t & 31)) & 1u;
+    tab[t] = (here && nletters <= maxletters) ? (unsigned char)rank : pad;
+    __syncthreads();
+    return nletters;
+}
+
+// sw_prep_code: blocks x < npad of pair y: bpad[front + i] = b[i] (bytes, zero padded), bpad16 (16-bit, padded with the never-matching
+// 0x100), bcode (letter codes 0..6, 7 outside the sequence and for alphabets of more than 7 letters) -- producer lane l reads
+// b[u-phi-l-1] for steps that reach phi+63 rows above and ~200 rows below the matrix (those cells are never stored).  Block (0,0)
+// also publishes the code table atab and zeroes the arg-max key.  Blocks x >= npad (pair 0 only): row 0 and column 0 of the
+// matrices the two-column kernel does not write itself (H int32 / int64, P int32 / int8; either may be NULL; skip_row0: a band's
+// row 0 is its halo row -- H comes from the kernel, P belongs to the band above).
+__global__ void __launch_bounds__(256) sw_prep_code(const unsigned char* __restrict__ b, int64_t rows, int64_t front, int64_t b_pstride,
+                                                    unsigned char* __restrict__ bpad, unsigned short* __restrict__ bpad16, unsigned char* __restrict__ bcode,
+                                                    const unsigned int* __restrict__ part, int npart, unsigned char* __restrict__ atab, int64_t per, int npad,
+                                                    void* H, int h_bytes, void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0,
+                                                    unsigned long long* key) {
+    if ((int)blockIdx.x >= npad) {
+        const int64_t e = ((int64_t)blockIdx.x - npad) * blockDim.x + threadIdx.x;   // element of [row 0 | column 0]
+        if (e < M && !skip_row0) {
+            if (H) { if (h_bytes == 8) ((int64_t*)H)[e] = 0; else ((int32_t*)H)[e] = 0; }
+            if (P) { if (p_bytes == 1) ((signed char*)P)[e] = 0; else ((int32_t*)P)[e] = 0; }
+        } else if (e >= M && e - M < rows1 - 1) {
+            const int64_t r = e - M + 1;
+            if (H) { if (h_bytes == 8) ((int64_t*)H)[r * M] = 0; else ((int32_t*)H)[r * M] = 0; }
+            if (P) { if (p_bytes == 1) ((signed char*)P)[r * M] = 0; else ((int32_t*)P)[r * M] = 0; }
+        }
+        return;
+    }
+    __shared__ unsigned char tab[256];
+    const int nletters = sw_code_table(part, npart, tab, 7, (unsigned char)7);
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        atab[threadIdx.x] = tab[threadIdx.x];
+        if (threadIdx.x == 0) *(unsigned int*)(atab + 256) = (unsigned int)nletters;
+        if (key && threadIdx.x < 2) key[threadIdx.x] = 0ull;
+    }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t pair = blockIdx.y;  // batch: one padded copy per problem
     if (i < per) {
@@ -1844,16 +1876,6 @@ __global__ void __launch_bounds__(256) sw_pad_b(const unsigned char* __restrict_
         bpad[pair * per + i] = ch;
         bpad16[pair * per + i] = in ? (unsigned short)ch : (unsigned short)0x100;  // 0x100 never equals a character
         bcode[pair * per + i] = in ? tab[ch] : (unsigned char)7;
-    }
-}
-
-// column 0 of the matrices the two-column kernel does not write itself (H int32, P int32 or int8; either may be NULL);
-// skip_row0: a band's row 0 is its halo row (H comes from the kernel, P belongs to the band above)
-__global__ void sw_zero_col0(void* H, int h_bytes, void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < rows1 && !(skip_row0 && r == 0)) {
-        if (H) { if (h_bytes == 8) ((int64_t*)H)[r * M] = 0; else ((int32_t*)H)[r * M] = 0; }
-        if (P) { if (p_bytes == 1) ((signed char*)P)[r * M] = 0; else ((int32_t*)P)[r * M] = 0; }
     }
 }
 

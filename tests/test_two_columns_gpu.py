@@ -1,5 +1,5 @@
 """GPU: the two-columns-per-lane fill kernel (sw_systolic2.inc) -- selected by the library for whole-matrix fills of one pair
-with int32 H and P and rows % 16 == 0 -- against the oracle, bit-exact, and against the one-column kernel (debug bit 14)."""
+with up to 7 letters -- against the oracle, bit-exact, and against the one-column kernel (debug bit 14)."""
 import numpy as np
 import pytest
 
@@ -20,10 +20,29 @@ def test_two_column_kernel_matches_oracle(engine, oracle, cols, rows):
     assert engine.get_option("last_strips2") == (cols + 125) // 126, "the two-column kernel was expected to run"
 
 
-def test_rows_not_a_multiple_of_16_fall_back(engine, oracle):
-    a, b = oracle.generate(500, 250, 78)
+@pytest.mark.parametrize("cols,rows", [(500, 250), (126, 1), (127, 15), (1000, 17), (2000, 2001), (333, 63), (4001, 1295), (150000 // 8, 2000)])
+def test_rows_not_a_multiple_of_16(engine, oracle, cols, rows):
+    """a short last block: its rows below the matrix are computed and their stores dropped (the reference's own sweep,
+    run-v0.sh:30-38, is 2000 rows x {2 .. 150000} columns)"""
+    a, b = oracle.generate(cols, rows, 78)
     check_against_oracle(engine, oracle, a, b)
-    assert engine.get_option("last_strips2") == 0
+    assert engine.get_option("last_strips2") == (cols + 125) // 126
+
+
+@pytest.mark.parametrize("mode", ["p8", "p8_only", "score_only", "h64"])
+def test_rows_not_a_multiple_of_16_other_formats(engine, oracle, mode):
+    import torch
+    a, b = oracle.generate(1260, 333, 84)
+    H, P, mp = oracle.fill(a, b)
+    out = engine.fill(a, b, h_dtype=torch.int64 if mode == "h64" else None, p_dtype=torch.int8 if mode.startswith("p8") else None,
+                      want_h=mode in ("p8", "h64"), want_p=mode != "score_only")
+    assert engine.get_option("last_strips2") == 10
+    r = out.result()
+    assert r["max_pos"] == mp and r["max_score"] == int(H.flat[mp])
+    if out.H is not None:
+        assert np.array_equal(out.H.cpu().numpy().astype(np.int32), H)
+    if out.P is not None:
+        assert np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
 
 
 @pytest.mark.parametrize("scores", [(5, -3, -4), (3, -3, 0), (2, 1, -3), (1, -1, -1)], ids=str)
