@@ -39,9 +39,10 @@ def counters(tag, kernel_substr):
 
 
 print("== bench lines")
+_steps = [ln[4:].strip() for ln in open(os.path.join(src, "ci.log")) if ln.startswith("=== ")] if os.path.exists(os.path.join(src, "ci.log")) else None
 for f in sorted(glob.glob(os.path.join(src, "bench*.log"))):
     d = bench_line(f)
-    if d:
+    if d and (_steps is None or os.path.basename(f)[:-4] in _steps):
         r = d.get("roofline", {})
         print(f"{os.path.basename(f)[:-4]:36s} {d['value']:9.1f} {d['unit']}  {d['ms_per_step']:9.4f} ms/step  n_gpus {d['n_gpus']}  "
               f"frac {r.get('frac', 0):.3f} ({r.get('bound', '-')})  tau {r.get('tau_step_ns', 0) or 0:.1f} ns  lag {r.get('strip_handoff_lag_ns', 0) or 0:.0f} ns")
@@ -99,9 +100,10 @@ json.dump(out, open(os.path.join(src, "r03_pmc_traffic.json"), "w"), indent=1)
 if copy:
     os.makedirs(prof, exist_ok=True)
     n = 0
+    steps = [ln[4:].strip() for ln in open(os.path.join(src, "ci.log")) if ln.startswith("=== ")]   # only what THIS run produced
     for f in sorted(glob.glob(os.path.join(src, "bench*.log"))):
         d = bench_line(f)
-        if d:
+        if d and os.path.basename(f)[:-4] in steps:
             json.dump(d, open(os.path.join(prof, "r03_" + os.path.basename(f)[:-4] + ".json"), "w"))
             n += 1
     for name, dst in (("ci.log", "r03_ci.log"), ("profile_summary.log", "r03_profile_summary.log"), ("r03_pmc_traffic.json", "r03_pmc_traffic.json"),

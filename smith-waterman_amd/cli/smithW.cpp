@@ -160,6 +160,18 @@ int main(int argc, char** argv) {
     CHECK(sw_fill_device(ctx, (const char*)d_a, cols, (const char*)d_b, rows, &sc, d_H, h64 ? 8 : 4, (int32_t*)d_P, nullptr, (sw_result*)d_res, nullptr));
     CHECK(sw_synchronize(ctx, nullptr));
 
+    if (backtrack) {   // ... and loads the traceback kernel (first use of a kernel pays for its code object): a walk of nothing on a 1 x 1 matrix
+        void *d_p1, *d_r1;
+        CHECK(sw_device_malloc(ctx, 4 * sizeof(int32_t), &d_p1));
+        CHECK(sw_device_malloc(ctx, sizeof(sw_result), &d_r1));
+        const int32_t zeros[4] = {0, 0, 0, 0}; const sw_result r0 = {0, 0, 0};
+        CHECK(sw_memcpy_h2d(ctx, d_p1, zeros, sizeof zeros));
+        CHECK(sw_memcpy_h2d(ctx, d_r1, &r0, sizeof r0));
+        CHECK(sw_traceback_device(ctx, (int32_t*)d_p1, 1, 1, 3, nullptr, 0, (sw_result*)d_r1, nullptr));
+        CHECK(sw_synchronize(ctx, nullptr));
+        sw_device_free(ctx, d_p1); sw_device_free(ctx, d_r1);
+    }
+
     double t0 = now_s();
     CHECK(sw_fill_device(ctx, (const char*)d_a, cols, (const char*)d_b, rows, &sc, d_H, h64 ? 8 : 4, (int32_t*)d_P, nullptr, (sw_result*)d_res, nullptr));
     CHECK(sw_synchronize(ctx, nullptr));
