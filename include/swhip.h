@@ -155,7 +155,10 @@ int sw_multi_nbands(sw_multi* m);
 double sw_multi_seconds(sw_multi* m);   /* wall time of the last sw_multi_fill */
 void sw_multi_free(sw_multi* m);
 
-/* Batch of npairs independent cols x rows problems (BASELINE config 5): pair k reads a at
+/* Batch of npairs independent cols x rows problems (BASELINE config 5; the reference handles one pair per process,
+ * serial_smithW.c:141-145 per pair).  Runs on the one-pair-per-wave kernel (csrc/sw_batch.hip) when the batch has at most 8
+ * distinct letters and the scores fit a signed byte -- the letter count is read back once per call, the one host round trip --
+ * and on the single-pair machinery otherwise; results are identical.  Pair k reads a at
  * d_a + k*a_stride and b at d_b + k*b_stride (b_stride a multiple of 16), writes d_results[k] (exact arg-max in
  * every mode) and, where given, its matrices at element offset k*(rows+1)*(cols+1).  d_H and/or d_P may be NULL. */
 int sw_batch_device(sw_ctx* ctx, const char* d_a, int64_t a_stride, int64_t cols, const char* d_b, int64_t b_stride,
@@ -185,7 +188,8 @@ int sw_align_auto(sw_ctx* ctx, const char* a, int64_t cols, const char* b, int64
 int sw_fill_cpu(const char* a, int64_t cols, const char* b, int64_t rows, const sw_scores* scores, int32_t* H, int32_t* P,
                 sw_result* result);
 
-/* ---- traceback: replaces backtrack(), serial_smithW.c:262-277.  Negates P along the path.
+/* ---- traceback: replaces backtrack(), serial_smithW.c:262-277.  Negates P along the path.  One wave walks 64 x 64 windows of P
+ * held in registers (csrc/sw_traceback.hip): ~35 ns per step instead of a memory latency.
  * d_path (optional) receives the visited linear indices (capacity path_cap);
  * d_result->path_len is set.  P[max_pos]==NONE (UB in the reference) == empty path. */
 int sw_traceback_device(sw_ctx* ctx, int32_t* d_P, int64_t cols, int64_t rows, int64_t max_pos,
@@ -217,7 +221,11 @@ int sw_row_checksums_device(sw_ctx* ctx, const void* d_X, int elem_bytes, int64_
  * same DRAM banks).  sw_alloc_outputs allocates up to `trials` candidate pairs (0 = 10; 1 = a plain allocation, no trial
  * fills), runs three fills of the caller's problem into each on the default stream and keeps the fastest; trial_ms
  * (optional, `trials` floats) receives the time of every candidate tried, 0 for those not needed.  The contents of the
- * returned buffers are the last trial fill.  Release with sw_free_outputs (d_P may sit inside a larger allocation). */
+ * returned buffers are the last trial fill.  Release with sw_free_outputs (d_P may sit inside a larger allocation).
+ * The trial fills run on the DEFAULT stream: d_a / d_b must be ready on the device when this is called (synchronise the stream that
+ * wrote them first).  The search temporarily allocates spacer blocks of 16-160 GiB to steer where P lands -- only while 8 GiB of
+ * head room remain, and released before the call returns; on a GPU shared with other processes pass trials = 1.
+ * (sw_multi_create tunes the placement of every band with the default scores {3,-3,-2}; results never depend on it.) */
 int sw_alloc_outputs(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
                      int h_elem_bytes, int p_elem_bytes, int trials, void** d_H, void** d_P, float* trial_ms);
 int sw_free_outputs(sw_ctx* ctx, void* d_H, void* d_P);
@@ -236,7 +244,7 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       4.5 strips per CU or a batch that fits the CUs at once, else 2)
  *   "consumers"         systolic: consumer waves per strip: 2, 3, 4; also 6, 7 with one strip per group (0: with one strip per
  *                       group 4 up to ~3.5e8 cells and 6 above, with two strips 4; 8 is taken as 7).  The two-columns-per-lane
- *                       kernel (whole-matrix or band fills of one pair with rows % 16 == 0; csrc/sw_systolic2.inc) takes 4..7 from
+ *                       kernel (whole-matrix or band fills of one pair, any number of rows; csrc/sw_systolic2.inc) takes 4..7 from
  *                       this option (0: 5 up to ~3.5e8 cells, 6 above) and runs 9 minus that many importer waves
  *   "store_policy"      systolic H/P stores: 0 by problem size, 1 write-back, 2 streaming (nt)
  *   "importers"         systolic, one strip per workgroup: waves polling the left neighbour's edge column, besides the one that
@@ -246,7 +254,10 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *   "band_wait_ms"      sw_fill_band_device: how long a strip waits for its halo granules before the launch aborts
  *                       with SW_ETIMEOUT (default 20000)
  *   "max_blocks"        cap of the resident grid (0 = all CUs); concurrent band launches partition the CUs with it
- *   "waves_per_block", "debug_flags", "debug_buf"   development aids */
+ *   "waves_per_block", "debug_flags", "debug_buf", "batch_lds"   development aids (debug_flags 131072: no scout workgroups,
+ *                       65536: batches on the single-pair machinery, 16384: one column per lane)
+ * sw_get_option also answers "last_grid", "last_strips", "last_strips2" (strips of the two-column kernel), "last_scouts"
+ * (scout workgroups of the last fill) and "last_batch_kernel" (1: the last batch ran one pair per wave). */
 int sw_set_option(sw_ctx* ctx, const char* name, int64_t value);
 int64_t sw_get_option(sw_ctx* ctx, const char* name);
 
