@@ -48,7 +48,7 @@ struct sw_ctx {
     unsigned int* d_edge4 = nullptr;    // perm producer: lane-63 columns as self-tagged 4-byte values
     size_t edge4_cap = 0;               // elements
     unsigned epoch8 = 0;                // 8-bit launch tag of those values
-    unsigned char* d_alpha = nullptr;   // [64..323] letter code table + letter count
+    unsigned char* d_alpha = nullptr;   // [64..323] letter code table + letter count; [512..1535] XCD of every workgroup of the running launch (sw_systolic2, xcd_mode)
     unsigned int* d_part = nullptr;     // sw_prep_scan: one 256-bit presence map of byte values per block (up to 2048 blocks)
     int64_t opt_debug = 0;
     int64_t opt_store_policy = 0;       // systolic H/P stores: 0 auto (by size), 1 write-back, 2 streaming (nt)
@@ -69,6 +69,8 @@ struct sw_ctx {
     int64_t last_grid = 0, last_strips = 0;
     int64_t last_strips2 = 0;           // strips of the two-column kernel in the last launch (0: not launched)
     int64_t last_scouts = 0;            // scout workgroups of that launch
+    int64_t last_xcd_mode = 0;          // that launch dealt its roles per XCD
+    bool xcd_round_robin = false;       // sw_xcc_probe saw workgroup i on XCD i % 8 (8 XCDs of 32 CUs)
     std::map<void*, void*> out_base;    // sw_alloc_outputs: pointer handed out -> allocation to free
 };
 
@@ -87,9 +89,21 @@ int sw_create(int device, sw_ctx** out) {
     c->num_cus = prop.multiProcessorCount;
     HIP_TRY(hipMalloc((void**)&c->d_key, 64));
     HIP_TRY(hipMemset(c->d_key, 0, 64));
-    HIP_TRY(hipMalloc((void**)&c->d_alpha, 512));
-    HIP_TRY(hipMemset(c->d_alpha, 0, 512));
+    HIP_TRY(hipMalloc((void**)&c->d_alpha, 2048));
+    HIP_TRY(hipMemset(c->d_alpha, 0, 2048));
     HIP_TRY(hipMalloc((void**)&c->d_part, 2048 * 32));
+    // Are the workgroups of a launch dealt round-robin to 8 XCDs of 32 CUs (workgroup i on XCD i % 8)?  The two-column kernel then
+    // places every scout on the XCD of the workgroups that read its edge column (sw_systolic2.inc).
+    if (c->num_cus == 256) {
+        unsigned int h[256];
+        hipLaunchKernelGGL(swk::sw_xcc_probe, dim3(256), dim3(768), 0, nullptr, c->d_part);
+        if (hipMemcpy(h, c->d_part, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            c->xcd_round_robin = true;
+            for (int i = 0; i < 256; ++i) c->xcd_round_robin = c->xcd_round_robin && h[i] == (unsigned)(i & 7);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     *out = c;
     return SW_OK;
 }
@@ -156,6 +170,8 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "last_strips")) return c->last_strips;
     if (!strcmp(name, "last_strips2")) return c->last_strips2;
     if (!strcmp(name, "last_scouts")) return c->last_scouts;
+    if (!strcmp(name, "last_xcd_mode")) return c->last_xcd_mode;
+    if (!strcmp(name, "xcd_round_robin")) return c->xcd_round_robin ? 1 : 0;
     if (!strcmp(name, "last_batch_kernel")) return c->last_batch_kernel;
     return -1;
 }
@@ -309,7 +325,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         const bool perm_ok = !halo_unbounded && p.mm <= 127 && p.mm >= -127 && p.xm <= 127 && p.xm >= -127 && gmax + 0x10000 + 1024 < (1ll << 24) &&
                              !(c->opt_debug & 16);
         if (perm_ok) {
-            const int64_t e4stride = ((rows + S + 160 + 3) / 4) * 4;
+            const int64_t e4stride = ((rows + S + 160 + 31) / 32) * 32;   // (whole 128-byte lines: strips written on different XCDs share none)
             const size_t need4 = (size_t)S * (size_t)e4stride * (size_t)j.npairs;
             if (need4 > c->edge4_cap) {
                 HIP_TRY(hipStreamSynchronize(stream));
@@ -367,7 +383,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         }
         const unsigned char* cbp = c->d_cb;
         bool launched = false;
-        c->last_strips2 = 0; c->last_scouts = 0;
+        c->last_strips2 = 0; c->last_scouts = 0; c->last_xcd_mode = 0;
         // Two matrix columns per lane (sw_systolic2.inc): half as many strips -- and row segments of 504 bytes per store -- for the
         // same work: 16384^2 +4 %, 8192^2 +11 %, 24576^2 +29 %, 32768^2 +32 %, 65536^2 +9 % over one column per lane.  Whole
         // matrix of one pair, int32 H and P both stored, rows a multiple of 16; the alphabet (found on the device) must allow the
@@ -406,6 +422,22 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 p2.nscout = scouts ? (int)nsc : 0;
                 p2.scout_double = scouts ? (int)ndouble : 0;
                 if (scouts) grid2 = (int)(S2 + nsc);
+                // Roles dealt per XCD (sw_systolic2.inc): an eighth of the fillers and the scouts that feed them on every XCD, so that
+                // an edge column is read on the XCD that wrote it -- out of its L2, without the trip through the memory fabric.  Needs the
+                // whole device (256 workgroups, one per CU, workgroup i on XCD i % 8).  (debug bit 23: off)
+                p2.xcd_mode = 0;
+                if (scouts && c->xcd_round_robin && avail >= 256 && S2 >= 16 && !(c->opt_debug & 8388608)) {
+                    bool fits = true;
+                    int wg = 0, dbl = 0;
+                    for (int x = 0; x < 8 && fits; ++x) {
+                        const int nf = (int)(S2 / 8) + (x < (int)(S2 % 8) ? 1 : 0), ns = x ? nf : nf - 1;
+                        const int ndx = std::max(0, ns - (32 - nf));
+                        fits = nf <= 31 && 2 * ndx <= ns;
+                        wg += ns - ndx; dbl += ndx;
+                    }
+                    if (fits) { p2.xcd_mode = 1; p2.nscout = wg; p2.scout_double = dbl; grid2 = 256; }
+                }
+                c->last_xcd_mode = p2.xcd_mode;
                 c->last_scouts = p2.nscout;
                 // row 0 and column 0 are not the kernel's: zeros, except a band's halo row (its H comes from the row above, written by
                 // the kernel; its P belongs to the band above)

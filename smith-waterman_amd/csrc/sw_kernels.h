@@ -56,7 +56,9 @@ struct FillParams {
     int h_bytes;                         // sw_systolic2: bytes per H element (4 or 8); sw_systolic carries it as a template parameter
     int scout_double;                    // sw_systolic2: the first scout_double scout workgroups carry two strips, the others one
     int nscout;                          // sw_systolic2: workgroups 0..nscout-1 only run the chain (two strips each) and leave the edge columns to the others
+    int xcd_mode;                        // sw_systolic2: 256 workgroups, roles dealt per XCD (workgroup i on XCD i % 8; nscout = scout workgroups in all)
 };
+constexpr int SW_XTAB_OFF = 448;         // atab + 448: unsigned int[256], XCD + 1 of every workgroup of the running sw_systolic2 launch (0: not there yet)
 constexpr int SW_PERM_PAD = -100;        // score of any cell outside the sequences (perm producer)
 
 // sw_batch.hip: one pair per wave (BASELINE config 5)
@@ -89,6 +91,7 @@ __global__ void sw_prep_scan(const unsigned char* a, int64_t cols, int64_t a_pst
 __global__ void sw_prep_code(const unsigned char* b, int64_t rows, int64_t front, int64_t b_pstride, unsigned char* bpad, unsigned short* bpad16,
                              unsigned char* bcode, const unsigned int* part, int npart, unsigned char* atab, int64_t per, int npad, void* H, int h_bytes,
                              void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0, unsigned long long* key);
+__global__ void sw_xcc_probe(unsigned int* xcc_of_block);
 __global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res, int n);
 template <typename PT>
 __global__ void sw_traceback_wave(PT* P, int64_t M, int64_t rows1, int64_t pstride, int64_t start_pos, int64_t* paths, int64_t cap, sw_result* res,

@@ -1789,6 +1789,13 @@ __global__ void __launch_bounds__(256) sw_wipe_u32(unsigned int* __restrict__ bu
         __hip_atomic_store((gu32*)(buf + i), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Which XCD does workgroup i of a launch run on?  (sw_create checks that it is i % 8 before sw_systolic2 may rely on it.)
+__global__ void sw_xcc_probe(unsigned int* xcc_of_block) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0) xcc_of_block[blockIdx.x] = xcc & 15u;
+}
+
 // ---- input preparation: two small kernels per fill (they used to be seven dispatches: two memsets + scan + coding + two row-0
 // memsets + a column-0 kernel, 72 us of a 0.97 ms fill in round 2's trace) ---------------------------------------------------
 // sw_prep_scan: which byte values occur in a and b (all pairs of a batch).  Every block writes ITS 256-bit presence map to
@@ -1867,6 +1874,7 @@ __global__ void __launch_bounds__(256) sw_prep_code(const unsigned char* __restr
         atab[threadIdx.x] = tab[threadIdx.x];
         if (threadIdx.x == 0) *(unsigned int*)(atab + 256) = (unsigned int)nletters;
         if (key && threadIdx.x < 2) key[threadIdx.x] = 0ull;
+        ((unsigned int*)(atab + SW_XTAB_OFF))[threadIdx.x] = 0u;   // sw_systolic2, xcd_mode: no workgroup of the coming launch has said where it runs
     }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t pair = blockIdx.y;  // batch: one padded copy per problem
