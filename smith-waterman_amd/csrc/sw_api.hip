@@ -51,6 +51,7 @@ struct sw_ctx {
     unsigned char* d_alpha = nullptr;   // [64..323] letter code table + letter count; [512..1535] XCD of every workgroup of the running launch (sw_systolic2, xcd_mode)
     unsigned int* d_part = nullptr;     // sw_prep_scan: one 256-bit presence map of byte values per block (up to 2048 blocks)
     int64_t opt_debug = 0;
+    int64_t opt_filler_hop_ps = 2400000, opt_filler_tau_ps = 26000, opt_filler_bw_gbs = 4200;   // pacing of the fillers behind scouts (sw_systolic2.inc)
     int64_t opt_store_policy = 0;       // systolic H/P stores: 0 auto (by size), 1 write-back, 2 streaming (nt)
     int64_t opt_xcd_order = 0;          // systolic: 1 = neighbouring strip groups on one XCD
     int64_t opt_importers = 0;          // systolic, one strip per workgroup: importer waves (as far as 12 waves allow); 0 = by problem size
@@ -134,6 +135,9 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "strips_per_group")) { c->opt_strips_per_group = v; return SW_OK; }
     if (!strcmp(name, "consumers")) { c->opt_consumers = v; return SW_OK; }
     if (!strcmp(name, "debug_flags")) { c->opt_debug = v; return SW_OK; }
+    if (!strcmp(name, "filler_hop_ps")) { c->opt_filler_hop_ps = v < 0 ? 0 : v; return SW_OK; }
+    if (!strcmp(name, "filler_tau_ps")) { c->opt_filler_tau_ps = v < 1000 ? 1000 : v; return SW_OK; }
+    if (!strcmp(name, "filler_bw_gbs")) { c->opt_filler_bw_gbs = v < 100 ? 100 : v; return SW_OK; }
     if (!strcmp(name, "pace_ps")) { c->opt_pace_ps = v; return SW_OK; }
     if (!strcmp(name, "store_policy")) { if (v < 0 || v > 2) return SW_EINVAL; c->opt_store_policy = v; return SW_OK; }
     if (!strcmp(name, "xcd_order")) { c->opt_xcd_order = v ? 1 : 0; return SW_OK; }
@@ -437,6 +441,11 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                     }
                     if (fits) { p2.xcd_mode = 1; p2.nscout = wg; p2.scout_double = dbl; grid2 = 256; }
                 }
+                // pacing of the fillers behind scouts (sw_systolic2.inc): estimates on the low side, so that nobody is held back more
+                // than the last filler's best case allows.  (options "filler_hop_ps" / "filler_tau_ps"; debug bit 27: off)
+                p2.filler_hop_ps = (scouts && !(c->opt_debug & 134217728)) ? (int)c->opt_filler_hop_ps : 0;
+                p2.filler_tau_ps = (int)c->opt_filler_tau_ps;
+                p2.filler_bw_gbs = (int)c->opt_filler_bw_gbs;
                 c->last_xcd_mode = p2.xcd_mode;
                 c->last_scouts = p2.nscout;
                 // row 0 and column 0 are not the kernel's: zeros, except a band's halo row (its H comes from the row above, written by

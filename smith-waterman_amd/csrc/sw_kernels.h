@@ -56,6 +56,7 @@ struct FillParams {
     int h_bytes;                         // sw_systolic2: bytes per H element (4 or 8); sw_systolic carries it as a template parameter
     int scout_double;                    // sw_systolic2: the first scout_double scout workgroups carry two strips, the others one
     int nscout;                          // sw_systolic2: workgroups 0..nscout-1 only run the chain (two strips each) and leave the edge columns to the others
+    int filler_hop_ps, filler_tau_ps, filler_bw_gbs;    // sw_systolic2 behind scouts: pacing of the fillers (sw_systolic2.inc), 0 = none
     int xcd_mode;                        // sw_systolic2: 256 workgroups, roles dealt per XCD (workgroup i on XCD i % 8; nscout = scout workgroups in all)
 };
 constexpr int SW_XTAB_OFF = 448;         // atab + 448: unsigned int[256], XCD + 1 of every workgroup of the running sw_systolic2 launch (0: not there yet)
