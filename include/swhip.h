@@ -245,19 +245,25 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *   "consumers"         systolic: consumer waves per strip: 2, 3, 4; also 6, 7 with one strip per group (0: with one strip per
  *                       group 4 up to ~3.5e8 cells and 6 above, with two strips 4; 8 is taken as 7).  The two-columns-per-lane
  *                       kernel (whole-matrix or band fills of one pair, any number of rows; csrc/sw_systolic2.inc) takes 4..7 from
- *                       this option (0: 5 up to ~3.5e8 cells, 6 above) and runs 9 minus that many importer waves
+ *                       this option (0: 7 behind scout workgroups, else 5 up to ~3.5e8 cells, 6 above) and runs 9 minus that many
+ *                       importer waves
  *   "store_policy"      systolic H/P stores: 0 by problem size, 1 write-back, 2 streaming (nt)
  *   "importers"         systolic, one strip per workgroup: waves polling the left neighbour's edge column, besides the one that
  *                       always does (0: 4 up to ~3.5e8 cells, 2 above; at most what 12 waves per workgroup leave)
  *   "xcd_order"         systolic: 1 = neighbouring strip groups run on the same XCD
  *   "pace_ps"           systolic: strip 0 releases one row per this many picoseconds (0 = unpaced)
+ *   "filler_hop_ps", "filler_tau_ps", "filler_bw_gbs"   two-column kernel behind scout workgroups: pacing of the workgroups that
+ *                       write H / P -- estimate of a strip hand-off (2400000 ps; 0 = no pacing), time per row of
+ *                       an unhindered strip (25000 ps), store bandwidth the strips share (4200 GB/s)
  *   "band_wait_ms"      sw_fill_band_device: how long a strip waits for its halo granules before the launch aborts
  *                       with SW_ETIMEOUT (default 20000)
  *   "max_blocks"        cap of the resident grid (0 = all CUs); concurrent band launches partition the CUs with it
  *   "waves_per_block", "debug_flags", "debug_buf", "batch_lds"   development aids (debug_flags 131072: no scout workgroups,
- *                       65536: batches on the single-pair machinery, 16384: one column per lane)
+ *                       8388608: scouts without the per-XCD dealing of the roles, 134217728: no pacing, 65536: batches on the
+ *                       single-pair machinery, 16384: one column per lane)
  * sw_get_option also answers "last_grid", "last_strips", "last_strips2" (strips of the two-column kernel), "last_scouts"
- * (scout workgroups of the last fill) and "last_batch_kernel" (1: the last batch ran one pair per wave). */
+ * (scout workgroups of the last fill), "last_xcd_mode" (1: that fill dealt its roles per XCD), "xcd_round_robin" (1: sw_create saw
+ * workgroup i of a launch on XCD i % 8) and "last_batch_kernel" (1: the last batch ran one pair per wave). */
 int sw_set_option(sw_ctx* ctx, const char* name, int64_t value);
 int64_t sw_get_option(sw_ctx* ctx, const char* name);
 

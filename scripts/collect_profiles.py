@@ -107,7 +107,8 @@ if copy:
             json.dump(d, open(os.path.join(prof, "r03_" + os.path.basename(f)[:-4] + ".json"), "w"))
             n += 1
     for name, dst in (("ci.log", "r03_ci.log"), ("profile_summary.log", "r03_profile_summary.log"), ("r03_pmc_traffic.json", "r03_pmc_traffic.json"),
-                      ("cli_16384.log", "r03_cli.log"), ("cli_2bands_1gpu_16384.log", "r03_cli_2bands_1gpu.log"), ("pytest_gpu.log", "r03_pytest_gpu.log")):
+                      ("cli_16384.log", "r03_cli.log"), ("cli_2bands_1gpu_16384.log", "r03_cli_2bands_1gpu.log"), ("pytest_gpu.log", "r03_pytest_gpu.log"),
+                      ("ubench_scope.log", "r03_ubench_scope.log")):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(prof, dst)); n += 1
     for d, tag in (("prof", ""), ("prof_batch", "_batch")):

@@ -24,6 +24,8 @@ step pytest_gpu 1100 python -m pytest tests -m gpu -x -q --durations=8
 fi
 # ---- BASELINE config 2 (the headline), with and without scouts / two columns per lane
 step bench 300 python bench.py
+step bench_no_pacing 200 python bench.py --steps 20 --warmup 3 --no-cpu --debug-flags 134217728
+step bench_no_xcd_roles 200 python bench.py --steps 20 --warmup 3 --no-cpu --debug-flags 142606336
 step bench_no_scouts 200 python bench.py --steps 20 --warmup 3 --no-cpu --debug-flags 131072
 step bench_one_column 200 python bench.py --steps 20 --warmup 3 --no-cpu --debug-flags 16384
 step bench_first_alloc 200 python bench.py --steps 20 --warmup 3 --no-cpu --placement-trials 1
@@ -31,6 +33,7 @@ step bench_p8 200 python bench.py --steps 20 --warmup 3 --no-cpu --p8
 # ---- other sizes
 step bench_i32_8k 200 python bench.py --steps 20 --warmup 3 --no-cpu --cols 8192 --rows 8192
 step bench_i32_12k 200 python bench.py --steps 20 --warmup 3 --no-cpu --cols 12288 --rows 12288
+step bench_i32_18k 200 python bench.py --steps 10 --warmup 3 --no-cpu --cols 18432 --rows 18432
 step bench_i32_20k 200 python bench.py --steps 10 --warmup 3 --no-cpu --cols 20480 --rows 20480
 step bench_i32_32k 300 python bench.py --steps 5 --warmup 2 --no-cpu --cols 32768 --rows 32768
 step bench_i32_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536
@@ -46,6 +49,7 @@ step bench_batch_100k_p8 400 python bench.py --mode batch --pairs 100000 --steps
 step bench_batch_100k_p8_traceback 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1 --store --p8 --no-h --traceback --no-cpu
 step bench_batch_100k_old_path 400 python bench.py --mode batch --pairs 100000 --steps 1 --warmup 1 --no-cpu --debug-flags 65536
 # ---- CLI: fill + traceback timing as the reference prints them
+step ubench_scope 120 ./tools/ubench_scope
 step cli_16384 200 ./smith-waterman_amd/smithW 16384 16384
 step cli_2bands_1gpu_16384 200 ./smith-waterman_amd/smithW --devices 0,0 16384 16384
 # ---- rocprofv3: kernel trace + stats of the default bench and of the batch kernel
