@@ -593,6 +593,8 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
     const int64_t total_letters = (cols + rows) * npairs;
     const unsigned nscan = (unsigned)std::max<int64_t>(1, std::min<int64_t>((total_letters + 4095) / 4096, 2048));
     hipLaunchKernelGGL(swk::sw_prep_scan, dim3(nscan), dim3(256), 0, stream, ua, cols, a_stride, ub, rows, b_stride, npairs, c->d_part);
+    // (one map for the half million blocks of sw_batch_codes: every one of them ORing 2048 maps by itself cost 29 ms per 100 000 pairs)
+    hipLaunchKernelGGL(swk::sw_prep_reduce, dim3(1), dim3(256), 0, stream, c->d_part, (int)nscan);
     const int front = 64;
     const int64_t per = ((rows + front + 80 + 72 + 15) / 16) * 16;   // (+40: the drain steps of the delayed int8 P stores read on)
     const int C = cols <= 256 ? 4 : cols <= 512 ? 8 : 16;
@@ -621,7 +623,7 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
     for (int64_t k0 = 0; k0 < npairs; k0 += chunk) {
         const int64_t n = std::min(chunk, npairs - k0);
         hipLaunchKernelGGL(swk::sw_batch_codes, dim3((unsigned)std::min<int64_t>((per + 255) / 256, 64), (unsigned)n), dim3(256), 0, stream, ub + k0 * b_stride, rows,
-                           b_stride, c->d_bcodes, per, front, (const unsigned int*)c->d_part, (int)nscan, c->d_alpha + 64);
+                           b_stride, c->d_bcodes, per, front, (const unsigned int*)c->d_part, 1, c->d_alpha + 64);
         if (k0 == 0) {   // the letter count (4 bytes) decides the path: the one host round trip of a batch call
             unsigned int nletters = 0;
             HIP_TRY(hipMemcpyAsync(&nletters, c->d_alpha + 64 + 256, 4, hipMemcpyDeviceToHost, stream));

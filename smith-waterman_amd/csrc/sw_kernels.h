@@ -93,6 +93,7 @@ __global__ void sw_prep_code(const unsigned char* b, int64_t rows, int64_t front
                              unsigned char* bcode, const unsigned int* part, int npart, unsigned char* atab, int64_t per, int npad, void* H, int h_bytes,
                              void* P, int p_bytes, int64_t M, int64_t rows1, int skip_row0, unsigned long long* key);
 __global__ void sw_xcc_probe(unsigned int* xcc_of_block);
+__global__ void sw_prep_reduce(unsigned int* part, int npart);
 __global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res, int n);
 template <typename PT>
 __global__ void sw_traceback_wave(PT* P, int64_t M, int64_t rows1, int64_t pstride, int64_t start_pos, int64_t* paths, int64_t cap, sw_result* res,

@@ -1784,8 +1784,13 @@ SW_INST(1, 7)
 // importers read it with agent-scope loads that are served from memory, and a plain memset's zeros can still sit in the
 // writing XCD's L2 at that time -- stale words of an earlier owner of the memory whose top byte happens to equal the
 // launch tag were then taken for data (seen as one wrong fill in ~200 around tags 0x38..0x40, the top bytes of floats).
+// (16 bytes per store: the 4-byte version took 8 ms for the 70 MB of a 32768^2 fill -- once every 255 fills, but inside somebody's timing.)
 __global__ void __launch_bounds__(256) sw_wipe_u32(unsigned int* __restrict__ buf, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    const size_t n4 = n / 4;
+    const sw_i32x4p z4 = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(buf + 4 * i), "v"(z4) : "memory");
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         __hip_atomic_store((gu32*)(buf + i), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -1818,6 +1823,20 @@ __global__ void __launch_bounds__(256) sw_prep_scan(const unsigned char* __restr
     for (int w = 0; w < 8; ++w) if (mine[w]) atomicOr(&seen[w], mine[w]);
     __syncthreads();
     if (threadIdx.x < 8) part[blockIdx.x * 8 + threadIdx.x] = seen[threadIdx.x];
+}
+
+// ORs the npart presence maps of sw_prep_scan into the first one (one block of 256 threads).
+__global__ void __launch_bounds__(256) sw_prep_reduce(unsigned int* part, int npart) {
+    __shared__ unsigned int acc[256];
+    const int w = threadIdx.x & 7;
+    unsigned int m = 0;
+    for (int k = threadIdx.x >> 3; k < npart; k += 32) m |= part[k * 8 + w];
+    acc[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        for (int k = 1; k < 32; ++k) m |= acc[k * 8 + w];
+        part[w] = m;
+    }
 }
 
 // the letter-code table from the partial presence maps: tab[v] = rank of byte value v among the values present (`maxcode` letters at
