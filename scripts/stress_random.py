@@ -11,11 +11,12 @@ orc = oracle_lib.Oracle()
 eng = sw.Engine(0)
 rng = np.random.default_rng(int(os.environ.get("SW_STRESS_SEED", "2025")))
 budget = float(os.environ.get('SW_STRESS_SECONDS', '170'))
-t0 = time.time(); tp = t0; n = n2 = nsc = ntb = bad = 0
+t0 = time.time(); tp = t0; n = n2 = nsc = nx = ntb = bad = 0
 modes = ["hp", "p8", "p8_only", "p32_only", "h_only", "score_only", "h64", "h64_p8"]
 while time.time() - t0 < budget:
     cols = int(rng.integers(1, 1600)) * 2 if rng.random() < 0.8 else int(rng.integers(1, 3000))
     rows = int(rng.integers(1, 60)) * 16 if rng.random() < 0.5 else int(rng.integers(1, 900))
+    if rng.random() < 0.15: cols, rows = int(rng.integers(2000, 21500)), int(rng.integers(1, 200))   # up to 171 strips: per-XCD roles, two-strip scouts
     mode = modes[int(rng.integers(0, len(modes)))]
     a, b = orc.generate(cols, rows, int(rng.integers(1, 1 << 30)))
     if rng.random() < 0.2: eng.set_option("max_blocks", int(rng.integers(1, 20)))
@@ -23,7 +24,7 @@ while time.time() - t0 < budget:
     out = eng.fill(a, b, h_dtype=torch.int64 if mode.startswith("h64") else None, p_dtype=torch.int8 if "p8" in mode else None, want_h=want_h, want_p=want_p)
     eng.set_option("max_blocks", 0)
     two = eng.get_option("last_strips2") > 0
-    n2 += two; nsc += eng.get_option("last_scouts") > 0
+    n2 += two; nsc += eng.get_option("last_scouts") > 0; nx += eng.get_option("last_xcd_mode") > 0
     H, P, mp = orc.fill(a, b)
     r = out.result()
     ok = r["max_pos"] == mp and r["max_score"] == int(H.flat[mp])
@@ -39,7 +40,7 @@ while time.time() - t0 < budget:
         print("MISMATCH", cols, rows, mode, "two-col" if two else "one-col", flush=True)
         if bad > 5: break
     if time.time() - tp > 30: tp = time.time(); print(f"... {n} fills, {bad} mismatches", flush=True)
-print(f"{n} random fills in random output modes ({n2} on the two-column kernel, {nsc} with scouts, {ntb} traced back), {bad} mismatches", flush=True)
+print(f"{n} random fills in random output modes ({n2} on the two-column kernel, {nsc} with scouts, {nx} with roles dealt per XCD, {ntb} traced back), {bad} mismatches", flush=True)
 # ---- batches
 t0 = time.time(); nb = npairs_total = badb = 0
 letters = np.frombuffer(b"ACGTNRYK", np.uint8)
