@@ -252,6 +252,8 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       always does (0: 4 up to ~3.5e8 cells, 2 above; at most what 12 waves per workgroup leave)
  *   "xcd_order"         systolic: 1 = neighbouring strip groups run on the same XCD
  *   "pace_ps"           systolic: strip 0 releases one row per this many picoseconds (0 = unpaced)
+ *   "xcd_chain"         two-column kernel without scout workgroups: the strips of a pass dealt per XCD, edge columns through that XCD's
+ *                       L2 (0: from 384 strips on, 1 on, 2 off)
  *   "filler_hop_ps", "filler_tau_ps", "filler_bw_gbs"   two-column kernel behind scout workgroups: pacing of the workgroups that
  *                       write H / P -- estimate of a strip hand-off (2400000 ps; 0 = no pacing), time per row of
  *                       an unhindered strip (25000 ps), store bandwidth the strips share (4200 GB/s)

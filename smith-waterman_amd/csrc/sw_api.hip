@@ -51,6 +51,7 @@ struct sw_ctx {
     unsigned char* d_alpha = nullptr;   // [64..323] letter code table + letter count; [512..1535] XCD of every workgroup of the running launch (sw_systolic2, xcd_mode)
     unsigned int* d_part = nullptr;     // sw_prep_scan: one 256-bit presence map of byte values per block (up to 2048 blocks)
     int64_t opt_debug = 0;
+    int64_t opt_xcd_chain = 0;          // two-column kernel without scouts: strips dealt per XCD (0 auto, 1 on, 2 off)
     int64_t opt_filler_hop_ps = 2400000, opt_filler_tau_ps = 25000, opt_filler_bw_gbs = 4200;   // pacing of the fillers behind scouts (sw_systolic2.inc)
     int64_t opt_store_policy = 0;       // systolic H/P stores: 0 auto (by size), 1 write-back, 2 streaming (nt)
     int64_t opt_xcd_order = 0;          // systolic: 1 = neighbouring strip groups on one XCD
@@ -135,6 +136,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "strips_per_group")) { c->opt_strips_per_group = v; return SW_OK; }
     if (!strcmp(name, "consumers")) { c->opt_consumers = v; return SW_OK; }
     if (!strcmp(name, "debug_flags")) { c->opt_debug = v; return SW_OK; }
+    if (!strcmp(name, "xcd_chain")) { c->opt_xcd_chain = v; return SW_OK; }
     if (!strcmp(name, "filler_hop_ps")) { c->opt_filler_hop_ps = v < 0 ? 0 : v; return SW_OK; }
     if (!strcmp(name, "filler_tau_ps")) { c->opt_filler_tau_ps = v < 1000 ? 1000 : v; return SW_OK; }
     if (!strcmp(name, "filler_bw_gbs")) { c->opt_filler_bw_gbs = v < 100 ? 100 : v; return SW_OK; }
@@ -430,6 +432,10 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 // an edge column is read on the XCD that wrote it -- out of its L2, without the trip through the memory fabric.  Needs the
                 // whole device (256 workgroups, one per CU, workgroup i on XCD i % 8).  (debug bit 23: off)
                 p2.xcd_mode = 0;
+                // measured (same buffers, classic against dealt per XCD): 24576^2 -1 %, 32768^2 -0.4 %, 65536^2 int32 +0.3 %, int64 H +2.3 %,
+                // 262144 x 32768 with int8 P +4.4 %: the classic hand-off is not the trip through memory (the polls of a filler queue behind
+                // its own H / P stores in the CU), so the gain is small and only where a workgroup runs several strips
+                const bool xcd_chain_pays = S2 >= 384;
                 if (scouts && c->xcd_round_robin && avail >= 256 && S2 >= 16 && !(c->opt_debug & 8388608)) {
                     bool fits = true;
                     int wg = 0, dbl = 0;
@@ -441,6 +447,11 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                     }
                     if (fits) { p2.xcd_mode = 1; p2.nscout = wg; p2.scout_double = dbl; grid2 = 256; }
                 }
+                // The classic chain (no room for scouts), dealt per XCD the same way: neighbouring strips on one XCD, edge columns through
+                // its L2.  (option "xcd_chain": 0 auto, 1 on, 2 off)
+                if (!scouts && c->xcd_round_robin && grid2 >= 64 && !(c->opt_debug & 8388608) &&
+                    (c->opt_xcd_chain == 1 || (c->opt_xcd_chain == 0 && xcd_chain_pays)))
+                    p2.xcd_mode = 2;
                 // pacing of the fillers behind scouts (sw_systolic2.inc): estimates on the low side, so that nobody is held back more
                 // than the last filler's best case allows.  (options "filler_hop_ps" / "filler_tau_ps"; debug bit 27: off)
                 p2.filler_hop_ps = (scouts && !(c->opt_debug & 134217728)) ? (int)c->opt_filler_hop_ps : 0;

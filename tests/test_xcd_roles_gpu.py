@@ -72,3 +72,22 @@ def test_repeated_fills_of_changing_sizes(engine, oracle):
         a, b = oracle.generate(126 * strips - k, 144 + 16 * k, 500 + k)
         check_against_oracle(engine, oracle, a, b)
         assert engine.get_option("last_xcd_mode") == 1
+
+
+@pytest.mark.parametrize("strips,max_blocks,rows", [(70, 0, 272), (200, 64, 144), (200, 100, 80), (133, 0, 333)])
+def test_classic_chain_dealt_per_xcd(engine, oracle, strips, max_blocks, rows):
+    """xcd_mode 2: no scouts (debug bit 17), the strips of a pass dealt per XCD, edge columns kept in the XCD's L2 except across the
+    seams; one pass, several passes (max_blocks), a last pass that is not full"""
+    _needs_round_robin(engine)
+    a, b = oracle.generate(126 * strips - 3, rows, 900 + strips)
+    engine.set_option("debug_flags", 131072)
+    engine.set_option("xcd_chain", 1)
+    engine.set_option("max_blocks", max_blocks)
+    try:
+        check_against_oracle(engine, oracle, a, b)
+        assert engine.get_option("last_scouts") == 0 and engine.get_option("last_xcd_mode") == 2
+        engine.set_option("xcd_chain", 2)
+        check_against_oracle(engine, oracle, a, b)
+        assert engine.get_option("last_xcd_mode") == 0
+    finally:
+        engine.set_option("debug_flags", 0); engine.set_option("xcd_chain", 0); engine.set_option("max_blocks", 0)
