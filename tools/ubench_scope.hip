@@ -15,6 +15,16 @@ __device__ __forceinline__ u64 ld(const u64* p) {
     if constexpr (LD == 2) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     if constexpr (LD == 3) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     if constexpr (LD == 4) asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (LD == 5 || LD == 6) {   // the scalar path (its own way to the L2, not behind the CU's vector stores): glc / plain + cache invalidate
+        u64 sv;
+        const u64* sp = (const u64*)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)p) + 0;   // (placeholder, replaced below)
+        (void)sp;
+        unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)((uintptr_t)p & 0xffffffffu)), hi = __builtin_amdgcn_readfirstlane((int)(unsigned)((uintptr_t)p >> 32));
+        u64 base = ((u64)hi << 32) | lo;
+        if constexpr (LD == 5) asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv) : "s"(base) : "memory");
+        else asm volatile("s_dcache_inv\n\ts_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv) : "s"(base) : "memory");
+        v = sv;
+    }
     return v;
 }
 template <int ST>
@@ -56,7 +66,7 @@ out:
 template <int ST, int LD>
 static void run(u64* d_out, u64* d_cell, int peer, u64& base) {
     const int iters = 2000;
-    static const char* nm[] = {"-", "sc0", "sc1", "sc0 sc1", "nt"};
+    static const char* nm[] = {"-", "sc0", "sc1", "sc0 sc1", "nt", "s_load glc", "s_dcache_inv+s_load"};
     hipMemset(d_cell, 0, 512);
     hipLaunchKernelGGL((pingpong<ST, LD>), dim3(256), dim3(64), 0, 0, d_out, d_cell, iters, peer, base);
     hipDeviceSynchronize();
@@ -83,6 +93,10 @@ int main() {
         run<1, 2>(d_out, d_cell, peer, base);
         run<0, 0>(d_out, d_cell, peer, base);
         run<3, 3>(d_out, d_cell, peer, base);
+        run<1, 5>(d_out, d_cell, peer, base);
+        run<2, 5>(d_out, d_cell, peer, base);
+        run<1, 6>(d_out, d_cell, peer, base);
+        run<2, 6>(d_out, d_cell, peer, base);
     }
     return 0;
 }
