@@ -19,6 +19,12 @@ root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 prof = os.path.join(root, "profiles")
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same directories: of several runs' traces only the newest counts"""
+    fs = glob.glob(pattern, recursive=True)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+
 def bench_line(path):
     try:
         for ln in open(path):
@@ -31,7 +37,7 @@ def bench_line(path):
 
 def counters(tag, kernel_substr):
     out = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(src, "pmc", tag, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(src, "pmc", tag, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if kernel_substr in row["Kernel_Name"]:
                 out[row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -49,14 +55,14 @@ for f in sorted(glob.glob(os.path.join(src, "bench*.log"))):
 
 print("== rocprofv3 kernel stats (top kernels)")
 for d in ("prof", "prof_batch"):
-    for f in glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True):
+    for f in newest(os.path.join(src, d, "**", "*kernel_stats.csv")):
         for i, row in enumerate(csv.DictReader(open(f))):
             if i < 5:
                 print(f"{d:11s} {row['Name'][:70]:70s} calls {row['Calls']:>5s} avg {float(row['AverageNs']) / 1e3:10.1f} us  {row['Percentage']}%")
 
 # the timed launches of the default bench: the last launch is the stamped one (chain_stamps), the `steps` before it are timed
 timed = None
-for f in glob.glob(os.path.join(src, "prof", "**", "*kernel_trace.csv"), recursive=True):
+for f in newest(os.path.join(src, "prof", "**", "*kernel_trace.csv")):
     rows = list(csv.DictReader(open(f)))
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if "sw_systolic2" in r["Kernel_Name"]]
     if len(d) >= 21:
@@ -68,7 +74,7 @@ for f in glob.glob(os.path.join(src, "prof", "**", "*kernel_trace.csv"), recursi
         per = [(int(big[i + 1]["Start_Timestamp"]) - int(big[i]["Start_Timestamp"])) for i in range(len(big) - 1)]
         timed["start_to_start_avg_ms"] = sum(per) / len(per) / 1e6
         print("== timed launches of the default bench:", json.dumps(timed))
-for f in glob.glob(os.path.join(src, "prof_batch", "**", "*kernel_trace.csv"), recursive=True):
+for f in newest(os.path.join(src, "prof_batch", "**", "*kernel_trace.csv")):
     rows = list(csv.DictReader(open(f)))
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if "sw_batch_wave" in r["Kernel_Name"]]
     if d:
@@ -112,9 +118,9 @@ if copy:
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(prof, dst)); n += 1
     for d, tag in (("prof", ""), ("prof_batch", "_batch")):
-        for f in glob.glob(os.path.join(src, d, "**", "*kernel_stats.csv"), recursive=True):
+        for f in newest(os.path.join(src, d, "**", "*kernel_stats.csv")):
             shutil.copy(f, os.path.join(prof, f"r03_kernel_stats{tag}.csv")); n += 1
-        for f in glob.glob(os.path.join(src, d, "**", "*kernel_trace.csv"), recursive=True):
+        for f in newest(os.path.join(src, d, "**", "*kernel_trace.csv")):
             # the trace is long (one line per launch): keep the last 400 lines
             lines = open(f).read().splitlines()
             open(os.path.join(prof, f"r03_kernel_trace{tag}.csv"), "w").write("\n".join(lines[:1] + lines[1:][-400:]) + "\n"); n += 1
