@@ -409,7 +409,7 @@ def main():
     ap.add_argument("--ns", type=int, default=0, help="systolic: strips per workgroup")
     ap.add_argument("--nc", type=int, default=0, help="systolic: consumer waves per strip")
     ap.add_argument("--p8", action="store_true", help="compact predecessor matrix: int8 P")
-    ap.add_argument("--placement-trials", type=int, default=10,
+    ap.add_argument("--placement-trials", type=int, default=16,
                     help="pair mode: candidate H/P placements sw_alloc_outputs may try before the timed region (1 = plain allocation)")
     ap.add_argument("--store-policy", type=int, default=0, help="systolic H/P stores: 0 auto, 1 write-back, 2 streaming")
     ap.add_argument("--importers", type=int, default=0)

@@ -218,7 +218,7 @@ int sw_row_checksums_device(sw_ctx* ctx, const void* d_X, int elem_bytes, int64_
 
 /* ---- output buffers placed for speed -------------------------------------------------------
  * Where H and P lie in physical memory moves a 16384^2 fill by up to 25 % (their two store streams can meet in the
- * same DRAM banks).  sw_alloc_outputs allocates up to `trials` candidate pairs (0 = 10, or 1 while H + P stay below 512 MiB: such a
+ * same DRAM banks).  sw_alloc_outputs allocates up to `trials` candidate pairs (0 = 16, or 1 while H + P stay below 512 MiB: such a
  * fill is not bound by its stores; 1 = a plain allocation, no trial fills), runs three fills of the caller's problem into each on the default stream and keeps the fastest; trial_ms
  * (optional, `trials` floats) receives the time of every candidate tried, 0 for those not needed.  The contents of the
  * returned buffers are the last trial fill.  Release with sw_free_outputs (d_P may sit inside a larger allocation).

@@ -275,7 +275,7 @@ class Engine:
         t = self.torch
         h_dtype = h_dtype or t.int32
         p_dtype = p_dtype or t.int32
-        n = trials if trials > 0 else 10
+        n = trials if trials > 0 else 16
         ms = (ctypes.c_float * n)()
         dH, dP = _vp(), _vp()
         sc = _Scores(*scores)

@@ -857,7 +857,7 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
     const size_t cells = (size_t)(cols + 1) * (size_t)(rows + 1);
     const size_t hbytes = cells * (size_t)h_elem_bytes, pbytes = cells * (size_t)p_elem_bytes;
     // (below half a GiB of output the strip chain bounds a fill, not the stores: no search -- its spacer allocations alone take seconds)
-    if (trials <= 0) trials = (hbytes + pbytes < (512ull << 20)) ? 1 : 10;
+    if (trials <= 0) trials = (hbytes + pbytes < (512ull << 20)) ? 1 : 16;
     const size_t phase = 4u << 20;
     struct Cand { void* H; void* Pbase; void* P; void* spacer; float ms; };
     std::vector<Cand> cands;
@@ -882,8 +882,9 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
         // 1.12 ms when H and P lie on different sides of the 64 GiB mark and 1.38-1.47 ms when they share a side, whatever
         // their distance.  So from the second candidate on a spacer of 64 GiB (then 32, 96, 48, 80) is allocated between
         // H and P -- and released again when the search ends: no memory stays held.
-        static const int kSpacerGiB[10] = {0, 64, 96, 32, 128, 48, 160, 80, 16, 112};
-        size_t sp = (i > 0 && hbytes < (8ull << 30)) ? (size_t)kSpacerGiB[i % 10] << 30 : 0;
+        // (a box where five of the first six candidates were slow has been seen: the search goes on to sixteen before it settles for a slow one)
+        static const int kSpacerGiB[16] = {0, 64, 96, 32, 128, 48, 160, 80, 16, 112, 144, 24, 176, 72, 104, 56};
+        size_t sp = (i > 0 && hbytes < (8ull << 30)) ? (size_t)kSpacerGiB[i % 16] << 30 : 0;
         if (sp) {
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < sp + pbytes + (8ull << 30)) sp = 0;   // not enough head room: plain candidate
