@@ -43,6 +43,7 @@ step bench_h64_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 6553
 step bench_band_n8_shape_p8 500 python bench.py --mode bands --cols 262144 --rows 32768 --steps 3 --warmup 1 --p8
 step bench_config4_one_gpu_p_only 500 python bench.py --mode bands --cols 262144 --rows 262144 --p8 --no-h --steps 2 --warmup 1
 step bench_gpus2_gloo_self_spawned 500 python bench.py --gpus 2 --backend gloo --steps 3 --warmup 1 --cols 32768 --rows 32768
+step bench_gpus4_gloo_one_gpu 500 python bench.py --gpus 4 --backend gloo --steps 2 --warmup 1 --cols 32768 --rows 32768
 # ---- config 5
 step bench_batch_100k_scoreonly 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1
 step bench_batch_100k_p8 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1 --store --p8 --no-h --no-cpu
