@@ -187,6 +187,12 @@ int sw_align_auto(sw_ctx* ctx, const char* a, int64_t cols, const char* b, int64
                   int32_t* H, int32_t* P, sw_result* result, int* used_gpu);
 int sw_fill_cpu(const char* a, int64_t cols, const char* b, int64_t rows, const sw_scores* scores, int32_t* H, int32_t* P,
                 sw_result* result);
+/* The same with the reference's THREE executors (omp_smithW-v7-adaptive.cpp:304-396: serial / OpenMP / offload per diagonal):
+ * executor 0 = host fill, 1 = one GPU (ctx if given, else a context made on devices[0]), 2 = row bands over all `ndev` devices
+ * (sw_multi_*; an id may repeat).  N GPUs are used from multi_min_cells cells on (0 = 4e9, about 65536^2: below that a single pair
+ * is bound by its strip chain, which more GPUs do not shorten) or when H + P do not fit devices[0].  Same outputs as sw_align_auto. */
+int sw_align_auto_multi(sw_ctx* ctx, const int* devices, int ndev, const char* a, int64_t cols, const char* b, int64_t rows,
+                        const sw_scores* scores, int32_t* H, int32_t* P, sw_result* result, int* executor, int64_t multi_min_cells);
 
 /* ---- traceback: replaces backtrack(), serial_smithW.c:262-277.  Negates P along the path.  One wave walks 64 x 64 windows of P
  * held in registers (csrc/sw_traceback.hip): ~35 ns per step instead of a memory latency.
@@ -206,6 +212,25 @@ int sw_traceback_host_ex(void* P, int p_elem_bytes, int64_t cols, int64_t rows, 
  * int32 H/P layout"): d_P32[k] = (int32_t)d_P8[k] for k < count -- codes 0..3, and -1..-3 along a traced path.  The two
  * buffers must not overlap. */
 int sw_p8_to_p32_device(sw_ctx* ctx, const void* d_P8, int32_t* d_P32, int64_t count, void* stream);
+
+/* 2-bit predecessor matrix (the reference's own "keep less" variant is the rolling-buffer fill,
+ * rotated-cuda/sw-rotated-omp.cc:214-224): the codes 0..3 of serial_smithW.c:23-27 need two bits, so 262144^2 predecessors take
+ * 17 GB instead of 69 GB (int8) or 275 GB (the reference's int32).  Layout: 4 cells per byte, cell k (row-major linear index, as in
+ * P) in bits 2*(k&3)..2*(k&3)+1 of byte k>>2.  Two bits cannot hold the sign backtrack() leaves on a path (P[pos] *= PATH,
+ * serial_smithW.c:271): a traced path is a bitmap beside the matrix, bit k&31 of 32-bit word k>>5.
+ *   SW_P2_BYTES(count) / SW_PATHBITS_BYTES(count): buffer sizes for `count` cells (whole 32-cell groups)
+ *   sw_p_to_p2_device   packs an int8 (p_elem_bytes 1) or int32 (4) matrix; negative (traced) cells set their bit in d_pathbits
+ *                       (optional, may be NULL; every word of it is written)
+ *   sw_p2_to_p32_device the round trip to the reference layout: d_P32[k] = code, negated where d_pathbits (optional) marks it
+ *   sw_traceback_p2_device  backtrack() on the packed matrix: marks the path in d_pathbits (optional; zeroed by the caller),
+ *                       writes the visited indices to d_path (optional) and d_result->path_len -- same walk, same kernel family
+ *                       as sw_traceback_device */
+#define SW_P2_BYTES(count) ((((size_t)(count) + 31) / 32) * 8)
+#define SW_PATHBITS_BYTES(count) ((((size_t)(count) + 31) / 32) * 4)
+int sw_p_to_p2_device(sw_ctx* ctx, const void* d_P, int p_elem_bytes, void* d_P2, uint32_t* d_pathbits, int64_t count, void* stream);
+int sw_p2_to_p32_device(sw_ctx* ctx, const void* d_P2, const uint32_t* d_pathbits, int32_t* d_P32, int64_t count, void* stream);
+int sw_traceback_p2_device(sw_ctx* ctx, const void* d_P2, int64_t cols, int64_t rows, int64_t max_pos, uint32_t* d_pathbits,
+                           int64_t* d_path, int64_t path_cap, sw_result* d_result, void* stream);
 
 /* ---- verification helpers (not on the timed path) ------------------------------------------
  * Position-weighted row checksums of a device matrix with (rows1 x m) elements:

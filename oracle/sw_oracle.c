@@ -192,3 +192,104 @@ int64_t swo_fill_streaming(const char* a, int64_t cols, const char* b, int64_t r
     free(prev); free(cur);
     return maxPos;
 }
+
+/* ---- whole-matrix digests of problems too big to materialise (round 4) --------------------
+ * swo_fill_streaming + H-row checkpoints every `every` rows (ckpt: (rows/every + 1) x m int32, row k = H row k*every),
+ * from which swo_path_from_ckpt() re-derives P block by block (same cell rule, serial_smithW.c:192-234) and walks it
+ * exactly like backtrack() (serial_smithW.c:262-277).  Emits the path (walk order), and the per-row checksum DELTAS the
+ * negation adds to csP, so a test can compare the traced-back matrix too. */
+int64_t swo_fill_streaming_ckpt(const char* a, int64_t cols, const char* b, int64_t rows,
+                                const swo_scores* sc, uint64_t* csH, uint64_t* csP,
+                                int32_t* max_score, int64_t every, int32_t* ckpt,
+                                int64_t band_rows, int32_t* band_best, int64_t* band_pos) {
+    int64_t m = cols + 1;
+    int32_t* prev = (int32_t*)calloc((size_t)m, sizeof(int32_t));
+    int32_t* cur  = (int32_t*)calloc((size_t)m, sizeof(int32_t));
+    int64_t maxPos = 0; int32_t best = 0;
+    if (csH) csH[0] = 0;
+    if (csP) csP[0] = 0;
+    if (ckpt) memset(ckpt, 0, (size_t)m * sizeof(int32_t));
+    for (int64_t i = 1; i <= rows; i++) {
+        uint64_t sh = 0, sp = 0;
+        char bi = b[i - 1];
+        int32_t rbest = 0; int64_t rpos = 0;     /* first maximum of this row (bands: arg-max of rows lo+1..hi alone) */
+        cur[0] = 0;
+        for (int64_t j = 1; j < m; j++) {
+            int32_t up = prev[j] + sc->gap, left = cur[j - 1] + sc->gap;
+            int32_t diag = prev[j - 1] + ((a[j - 1] == bi) ? sc->match : sc->mismatch);
+            int32_t max = 0, pred = 0;
+            if (diag > max) { max = diag; pred = SWO_DIAGONAL; }
+            if (up > max)   { max = up;   pred = SWO_UP; }
+            if (left > max) { max = left; pred = SWO_LEFT; }
+            cur[j] = max;
+            uint64_t w = (uint64_t)(j + 1) * SWO_CS_MUL;
+            sh += (uint64_t)(uint32_t)max * w;
+            sp += (uint64_t)(uint32_t)pred * w;
+            if (max > rbest) { rbest = max; rpos = m * i + j; }
+        }
+        if (rbest > best) { best = rbest; maxPos = rpos; }
+        if (band_best && band_rows > 0) {
+            int64_t k = (i - 1) / band_rows;
+            if ((i - 1) % band_rows == 0) { band_best[k] = 0; band_pos[k] = 0; }
+            if (rbest > band_best[k]) { band_best[k] = rbest; band_pos[k] = rpos; }
+        }
+        if (csH) csH[i] = sh;
+        if (csP) csP[i] = sp;
+        if (ckpt && i % every == 0) memcpy(ckpt + (i / every) * m, cur, (size_t)m * sizeof(int32_t));
+        int32_t* t = prev; prev = cur; cur = t;
+    }
+    if (max_score) *max_score = best;
+    free(prev); free(cur);
+    return maxPos;
+}
+
+int64_t swo_path_from_ckpt(const char* a, int64_t cols, const char* b, int64_t rows,
+                           const swo_scores* sc, int64_t every, const int32_t* ckpt, int64_t maxPos,
+                           int64_t* path, int64_t path_cap, uint64_t* csP_delta) {
+    int64_t m = cols + 1, len = 0;
+    int64_t i = maxPos / m, j = maxPos % m;
+    (void)rows;
+    int8_t* Pb = (int8_t*)malloc((size_t)every * (size_t)m);
+    int32_t* prev = (int32_t*)malloc((size_t)m * sizeof(int32_t));
+    int32_t* cur  = (int32_t*)malloc((size_t)m * sizeof(int32_t));
+    int done = 0;
+    if (i == 0 || j == 0) done = 1;     /* P[maxPos] == NONE: empty path, as swo_backtrack */
+    while (!done) {
+        /* block of rows r0+1 .. r1 that holds row i; only columns 0..j can be visited from here on */
+        int64_t k = (i - 1) / every, r0 = k * every, r1 = i, w = j + 1;
+        memcpy(prev, ckpt + k * m, (size_t)w * sizeof(int32_t));
+        for (int64_t r = r0 + 1; r <= r1; r++) {
+            char bi = b[r - 1];
+            int8_t* prow = Pb + (r - r0 - 1) * m;
+            cur[0] = 0; prow[0] = 0;
+            for (int64_t c = 1; c < w; c++) {
+                int32_t up = prev[c] + sc->gap, left = cur[c - 1] + sc->gap;
+                int32_t diag = prev[c - 1] + ((a[c - 1] == bi) ? sc->match : sc->mismatch);
+                int32_t max = 0, pred = 0;
+                if (diag > max) { max = diag; pred = SWO_DIAGONAL; }
+                if (up > max)   { max = up;   pred = SWO_UP; }
+                if (left > max) { max = left; pred = SWO_LEFT; }
+                cur[c] = max; prow[c] = (int8_t)pred;
+            }
+            int32_t* t = prev; prev = cur; cur = t;
+        }
+        /* walk inside the block */
+        while (i > r0) {
+            int32_t p = Pb[(i - r0 - 1) * m + j];
+            if (p == SWO_NONE) { done = 1; break; }
+            if (path && len < path_cap) path[len] = i * m + j;
+            if (csP_delta) {
+                uint64_t wgt = (uint64_t)(j + 1) * SWO_CS_MUL;
+                csP_delta[i] += (uint64_t)(uint32_t)(-p) * wgt - (uint64_t)(uint32_t)p * wgt;
+            }
+            len++;
+            if (p == SWO_DIAGONAL) { i--; j--; }
+            else if (p == SWO_UP)  { i--; }
+            else                   { j--; }
+            if (j == 0) { done = 1; break; }   /* column 0 is NONE everywhere */
+        }
+        if (i == 0) done = 1;                  /* row 0 is NONE everywhere */
+    }
+    free(Pb); free(prev); free(cur);
+    return len;
+}

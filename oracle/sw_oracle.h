@@ -75,6 +75,20 @@ int64_t swo_fill_streaming(const char* a, int64_t cols, const char* b, int64_t r
                            const swo_scores* sc, uint64_t* csH, uint64_t* csP,
                            int32_t* max_score, int32_t* bottom_row);
 
+/* Round 4: whole-matrix digests for sizes whose P does not fit host memory.  The streaming fill above plus H-row
+ * checkpoints every `every` rows (ckpt holds rows/every + 1 rows of m int32; row 0 = zeros), and a traceback that
+ * re-derives P block by block from them (serial_smithW.c:262-277 on serial_smithW.c:192-234's P).  csP_delta[i]
+ * (rows+1 entries, caller-zeroed) receives what negating the path adds to the row checksum of P.
+ * band_best / band_pos (optional, ceil(rows/band_rows) entries): arg-max of every band of band_rows rows taken alone
+ * (highest score, lowest linear index of the WHOLE matrix; 0 / 0 when the band is all zero). */
+int64_t swo_fill_streaming_ckpt(const char* a, int64_t cols, const char* b, int64_t rows,
+                                const swo_scores* sc, uint64_t* csH, uint64_t* csP,
+                                int32_t* max_score, int64_t every, int32_t* ckpt,
+                                int64_t band_rows, int32_t* band_best, int64_t* band_pos);
+int64_t swo_path_from_ckpt(const char* a, int64_t cols, const char* b, int64_t rows,
+                           const swo_scores* sc, int64_t every, const int32_t* ckpt, int64_t maxPos,
+                           int64_t* path, int64_t path_cap, uint64_t* csP_delta);
+
 #ifdef __cplusplus
 }
 #endif

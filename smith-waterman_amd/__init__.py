@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -66,6 +67,11 @@ ABI = {
     "sw_multi_seconds": (ctypes.c_double, [_vp]),
     "sw_multi_free": (None, [_vp]),
     "sw_align_auto": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result), ctypes.POINTER(_i32)]),
+    "sw_align_auto_multi": (_i32, [_vp, ctypes.POINTER(_i32), _i32, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result),
+                                   ctypes.POINTER(_i32), _i64]),
+    "sw_p_to_p2_device": (_i32, [_vp, _vp, _i32, _vp, _vp, _i64, _vp]),
+    "sw_p2_to_p32_device": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "sw_traceback_p2_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
     "sw_fill_cpu": (_i32, [_vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result)]),
     "sw_fill_host": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _vp, _vp, ctypes.POINTER(_Result)]),
     "sw_traceback_device": (_i32, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _vp]),
@@ -171,6 +177,14 @@ class Fill:
     cols: int
     rows: int
 
+    def free(self):
+        """Release a pair that came from Engine.alloc_outputs now (sw_free_outputs); the tensors must not be used afterwards."""
+        owner = getattr(self, "_owner", None)
+        self.H = self.P = None
+        if owner is not None:
+            owner.free()
+            self._owner = None
+
     def result(self):
         r = self.res.cpu().tolist()
         if r[2] < 0:
@@ -187,14 +201,16 @@ class _RawDevice:
 
 
 class _Outputs:
-    """Keeps a sw_alloc_outputs pair alive; released with sw_free_outputs."""
+    """Keeps a sw_alloc_outputs pair alive; released with sw_free_outputs when the last tensor that views it is dropped (the tensors
+    hold this object through _RawDevice), by Fill.free(), or at the latest by Engine.close().  The engine only keeps a WEAK
+    reference: a pair whose Fill was dropped is freed by the garbage collector, not held until the engine goes."""
 
     def __init__(self, engine, dH, dP):
         self.engine, self.dH, self.dP = engine, dH, dP
-        engine._outputs.append(self)
+        engine._outputs.add(self)
 
     def free(self):
-        """sw_free_outputs, once (Engine.close() frees whatever is still alive: the pair must not outlive its context)."""
+        """sw_free_outputs, once (the pair must not outlive its context)."""
         if self.dH is None and self.dP is None:
             return
         try:
@@ -203,10 +219,6 @@ class _Outputs:
         except Exception:
             pass
         self.dH = self.dP = None
-        try:
-            self.engine._outputs.remove(self)
-        except ValueError:
-            pass
 
     __del__ = free
 
@@ -223,7 +235,7 @@ class Engine:
         self.device = device
         torch.cuda.set_device(device)
         h = _vp()
-        self._outputs = []          # live sw_alloc_outputs pairs (freed at the latest by close())
+        self._outputs = weakref.WeakSet()   # live sw_alloc_outputs pairs (weak: dropping a Fill frees its pair; close() frees survivors)
         _check(lib().sw_create(device, ctypes.byref(h)))
         self._h = h
 
@@ -381,10 +393,6 @@ class Engine:
                 if store_h is None or store_h:
                     H = t.empty((npairs, rows + 1, cols + 1), dtype=t.int32, device=dev)
                 P = t.empty((npairs, rows + 1, cols + 1), dtype=p_dtype or t.int32, device=dev)
-                if os.environ.get("SW_P_SHIFT") and P.dtype == t.int8:   # alignment experiments: P starts SW_P_SHIFT bytes off a 256-byte boundary
-                    flat = t.empty(P.numel() + 256, dtype=t.int8, device=dev)
-                    sh = int(os.environ["SW_P_SHIFT"])
-                    P = flat[sh:sh + P.numel()].view(npairs, rows + 1, cols + 1)
         sc = _Scores(*scores)
         _check(lib().sw_batch_device_ex(self._h, d_a.data_ptr(), d_a.shape[1], cols, d_b.data_ptr(), d_b.shape[1], rows, npairs, ctypes.byref(sc),
                                         H.data_ptr() if H is not None else None, P.data_ptr() if P is not None else None,
@@ -429,6 +437,36 @@ class Engine:
         out = t.empty(P8.shape, dtype=t.int32, device=P8.device)
         _check(lib().sw_p8_to_p32_device(self._h, P8.data_ptr(), out.data_ptr(), P8.numel(), self._stream()))
         return out
+
+    def pack_p2(self, P, want_bits: bool = True):
+        """int8 / int32 predecessor matrix -> the 2-bit format (sw_p_to_p2_device): (P2 uint8 tensor with 4 cells per byte, path bitmap
+        int32 tensor with 1 bit per cell -- set where P was negative, i.e. on a traced path -- or None)."""
+        t = self.torch
+        n = P.numel()
+        P2 = t.empty(((n + 31) // 32) * 8, dtype=t.uint8, device=P.device)
+        bits = t.empty((n + 31) // 32, dtype=t.int32, device=P.device) if want_bits else None
+        _check(lib().sw_p_to_p2_device(self._h, P.data_ptr(), P.element_size(), P2.data_ptr(), bits.data_ptr() if want_bits else None, n, self._stream()))
+        return P2, bits
+
+    def unpack_p2(self, P2, bits, shape):
+        """2-bit matrix (+ optional path bitmap) -> the reference's int32 layout (sw_p2_to_p32_device)."""
+        t = self.torch
+        out = t.empty(shape, dtype=t.int32, device=P2.device)
+        _check(lib().sw_p2_to_p32_device(self._h, P2.data_ptr(), bits.data_ptr() if bits is not None else None, out.data_ptr(), out.numel(), self._stream()))
+        return out
+
+    def traceback_p2(self, P2, cols: int, rows: int, max_pos: int, bits=None, want_path: bool = True):
+        """backtrack() on a 2-bit matrix: the path is marked in `bits` (zeroed by the caller) instead of negating P.  Returns the path
+        indices (or the length)."""
+        t = self.torch
+        cap = cols + rows + 2
+        path = t.zeros(cap if want_path else 1, dtype=t.int64, device=P2.device)
+        res = t.zeros(3, dtype=t.int64, device=P2.device)
+        _check(lib().sw_traceback_p2_device(self._h, P2.data_ptr(), cols, rows, int(max_pos), bits.data_ptr() if bits is not None else None,
+                                            path.data_ptr() if want_path else None, cap, res.data_ptr(), self._stream()))
+        self.synchronize()
+        n = int(res[2].item())
+        return path[:n].cpu().numpy() if want_path else n
 
     def synchronize(self):
         _check(lib().sw_synchronize(self._h, self._stream()))
@@ -521,13 +559,23 @@ def _hip_d2h(arr: np.ndarray, dptr: int):
     arr.view(np.uint8).reshape(-1)[:] = t.cpu().numpy()
 
 
-def align_auto(a, b, scores=DEFAULT_SCORES, engine: "Engine | None" = None):
-    """sw_align_auto: host fill for tiny problems, the GPU of `engine` otherwise; host traceback.  Returns dict like smith_waterman()."""
+def align_auto(a, b, scores=DEFAULT_SCORES, engine: "Engine | None" = None, devices=None, multi_min_cells: int = 0):
+    """sw_align_auto: host fill for tiny problems, the GPU of `engine` otherwise; host traceback.  With `devices` (a list of GPU ids,
+    ids may repeat) sw_align_auto_multi: host / one GPU / row bands over all of them, chosen by size.  Returns dict like
+    smith_waterman() plus used_gpu and executor (0 host, 1 one GPU, 2 several)."""
     a, b = _as_seq(a).copy(), _as_seq(b).copy()
     cols, rows = len(a), len(b)
     H = np.zeros((rows + 1, cols + 1), np.int32)
     P = np.zeros((rows + 1, cols + 1), np.int32)
     sc, r, used = _Scores(*scores), _Result(), _i32()
-    _check(lib().sw_align_auto(engine._h if engine is not None else None, a.ctypes.data, cols, b.ctypes.data, rows, ctypes.byref(sc),
-                               H.ctypes.data, P.ctypes.data, ctypes.byref(r), ctypes.byref(used)))
-    return {"H": H, "P": P, "max_pos": r.max_pos, "max_score": r.max_score, "path_len": r.path_len, "used_gpu": bool(used.value)}
+    h = engine._h if engine is not None else None
+    if devices is None:
+        _check(lib().sw_align_auto(h, a.ctypes.data, cols, b.ctypes.data, rows, ctypes.byref(sc), H.ctypes.data, P.ctypes.data, ctypes.byref(r),
+                                   ctypes.byref(used)))
+        ex = 1 if used.value else 0
+    else:
+        dv = (_i32 * max(1, len(devices)))(*devices)
+        _check(lib().sw_align_auto_multi(h, dv, len(devices), a.ctypes.data, cols, b.ctypes.data, rows, ctypes.byref(sc), H.ctypes.data, P.ctypes.data,
+                                         ctypes.byref(r), ctypes.byref(used), multi_min_cells))
+        ex = used.value
+    return {"H": H, "P": P, "max_pos": r.max_pos, "max_score": r.max_score, "path_len": r.path_len, "used_gpu": ex > 0, "executor": ex}

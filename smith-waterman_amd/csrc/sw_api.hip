@@ -50,6 +50,10 @@ struct sw_ctx {
     unsigned epoch8 = 0;                // 8-bit launch tag of those values
     unsigned char* d_alpha = nullptr;   // [64..323] letter code table + letter count; [512..1535] XCD of every workgroup of the running launch (sw_systolic2, xcd_mode)
     unsigned int* d_part = nullptr;     // sw_prep_scan: one 256-bit presence map of byte values per block (up to 2048 blocks)
+    unsigned int* d_sync = nullptr;     // one-launch fills (sw_systolic2's prologue / epilogue): barrier and exit counters, presence map; zero between launches
+    unsigned char* d_priv = nullptr; size_t priv_cap = 0;   // ... and every workgroup's own padded copy of b + letter codes
+    bool key_dirty = false;             // d_key was left non-zero by a launch that does not re-arm it (everything but the one-launch fill)
+    bool last_fused = false;            // the last launch_fill reports by itself (no sw_finalize behind it)
     int64_t opt_debug = 0;
     int64_t opt_xcd_chain = 0;          // two-column kernel without scouts: strips dealt per XCD (0 auto, 1 on, 2 off)
     int64_t opt_filler_hop_ps = 2400000, opt_filler_tau_ps = 25000, opt_filler_bw_gbs = 4200;   // pacing of the fillers behind scouts (sw_systolic2.inc)
@@ -94,6 +98,8 @@ int sw_create(int device, sw_ctx** out) {
     HIP_TRY(hipMalloc((void**)&c->d_alpha, 2048));
     HIP_TRY(hipMemset(c->d_alpha, 0, 2048));
     HIP_TRY(hipMalloc((void**)&c->d_part, 2048 * 32));
+    HIP_TRY(hipMalloc((void**)&c->d_sync, 256));
+    HIP_TRY(hipMemset(c->d_sync, 0, 256));
     // Are the workgroups of a launch dealt round-robin to 8 XCDs of 32 CUs (workgroup i on XCD i % 8)?  The two-column kernel then
     // places every scout on the XCD of the workgroups that read its edge column (sw_systolic2.inc).
     if (c->num_cus == 256) {
@@ -119,6 +125,8 @@ void sw_destroy(sw_ctx* c) {
     if (c->d_edge4) (void)hipFree(c->d_edge4);
     if (c->d_alpha) (void)hipFree(c->d_alpha);
     if (c->d_part) (void)hipFree(c->d_part);
+    if (c->d_sync) (void)hipFree(c->d_sync);
+    if (c->d_priv) (void)hipFree(c->d_priv);
     if (c->d_keys) (void)hipFree(c->d_keys);
     if (c->d_bcodes) (void)hipFree(c->d_bcodes);
     if (c->d_bnd) (void)hipFree(c->d_bnd);
@@ -223,6 +231,7 @@ struct FillJob {
     int64_t total_rows = 0;       // band: rows of the whole matrix (bounds the scores a halo can carry)
     bool reserve_only = false;    // size the per-context workspaces for this job and return: nothing is launched
     bool zero_key = false;        // the preparation kernel also zeroes d_keys[0..1] (fill_one leaves that to it)
+    sw_result* d_result = nullptr;   // fill_one: where the result goes (a one-launch fill writes it by itself)
 };
 
 // called with g_dev[device].mu held: make `stream` wait for the fill enqueued last on another stream of this device.  The
@@ -251,6 +260,7 @@ struct DevOrder {   // RAII: device lock + stream ordering for one fill call
 static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStream_t stream) {
     const int64_t cols = j.cols, rows = j.rows;
     const bool systolic = (c->opt_engine == 0);
+    c->last_fused = false;
     const bool tile_features = j.d_left || j.d_right || j.stride != cols + 1 || j.npairs != 1 || !j.d_H || !j.d_P || j.d_top_gran || j.d_bot_gran;
     if (!systolic && tile_features) { set_err("tiles / batches / bands / matrix-less fills need the systolic engine (engine 0)"); return SW_EINVAL; }
     // (the caller holds the device lock and has ordered `stream` behind earlier fills: DevOrder)
@@ -349,13 +359,48 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             p.edge4 = c->d_edge4; p.e4stride = e4stride; p.edge4_pstride = (int64_t)S * e4stride;
             p.gbias = (c->epoch8 << 24) | 0x10000u;
         }
+        // Two matrix columns per lane (sw_systolic2.inc): half as many strips -- and row segments of 504 bytes per store -- for the
+        // same work: 16384^2 +4 %, 8192^2 +11 %, 24576^2 +29 %, 32768^2 +32 %, 65536^2 +9 % over one column per lane.  Whole
+        // matrix of one pair, int32 H and P both stored, rows a multiple of 16; the alphabet (found on the device) must allow the
+        // perm path -- so both kernels are enqueued and each checks for itself which of them has to work.  (debug bit 14: off)
+        // Also: int8 P, either matrix left out, and band-resident launches (halo row in, last row out as granules).
+        const bool base_mode = j.d_H && j.d_P && j.h_elem_bytes == 4 && j.p_elem_bytes == 4 && !j.d_top && !j.d_top_gran && !j.d_bot_gran;   // int32 H + P, whole matrix
+        // Where it pays: always for int32 H + P (8-byte stores of both matrices); in the other output formats while the strip chain
+        // (~3.1 us per 63-column strip) rather than the output volume (~3.2 TB/s) bounds the fill -- measured: 262144 x 32768 with
+        // int8 P +18 %, 131072^2 with int8 P -3 %, 262144^2 P-only -21 % (two byte stores per row and the in-block arg-max).
+        const double est_chain = (double)S * 3.1e-6;
+        const double est_hbm = (double)(cols + 1) * (double)(rows + 1) * ((j.d_H ? (double)j.h_elem_bytes : 0.0) + (j.d_P ? (double)j.p_elem_bytes : 0.0)) / 3.2e12;
+        const bool pays = (j.d_H && j.d_P && j.p_elem_bytes == 4) || (j.d_H && j.h_elem_bytes == 8) || est_chain >= (j.d_H ? 0.5 : 2.0) * est_hbm || (c->opt_debug & 32768);
+        int per_cu2 = 0;
+        bool two_cols = pays && perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 &&
+                              !j.d_left && !j.d_right && j.stride == cols + 1 && (rows % 16 == 0 || !j.d_bot_gran) && rows >= 1 && cols >= 1 &&   // (a band's last row leaves from a full block)
+                             
+                              (base_mode || (cols % 2 == 0)) &&   // (an odd column count leaves one lane with a single column: only the base mode handles it)
+                              !(c->opt_debug & (2 | 8 | 64 | 128 | 512 | 16384));
+        // The two-column kernel is ONE launch per fill: its prologue does what sw_prep_scan / sw_prep_code do for the other kernels (every
+        // workgroup keeps its own padded copy of b and of its letter codes) and its last workgroup out writes the result (sw_systolic2.inc).
+        // The strict one-launch path needs a result to write (a batch keeps its own keys and never comes here).
+        const int64_t priv_stride = ((2 * per + 255) / 256) * 256;
+        if (two_cols) {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, swk::sw_systolic2<6>, 768, 0));
+            if (per_cu2 < 1 || !j.d_result) two_cols = false;
+        }
+        if (two_cols) {
+            const size_t needp = (size_t)priv_stride * (size_t)per_cu2 * (size_t)c->num_cus;
+            if (needp > c->priv_cap) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (c->d_priv) HIP_TRY(hipFree(c->d_priv));
+                c->d_priv = nullptr; c->priv_cap = 0;
+                if (hipMalloc((void**)&c->d_priv, needp) != hipSuccess) { set_err("workspace allocation of %zu bytes failed", needp); return SW_ENOMEM; }
+                c->priv_cap = needp;
+            }
+        }
         if (j.reserve_only) {   // every workspace of this job exists now (and is wiped where fresh): wait for that, launch nothing
             HIP_TRY(hipStreamSynchronize(stream));
             return SW_OK;
         }
         // input preparation, two dispatches (sw_systolic.hip): presence maps of the letters, then codes / padded copies of b -- and, for
         // the two-column kernel, row 0 and column 0 of the matrices and the arg-max key
-        bool prepped = false;
         auto prepare = [&](void* zH, void* zP, bool skip_row0) {
             const int64_t total = (cols + rows) * j.npairs;
             const unsigned nscan = (unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 1023) / 1024, 2048));
@@ -365,7 +410,6 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             hipLaunchKernelGGL(swk::sw_prep_code, dim3(npad + nzero, (unsigned)j.npairs), dim3(256), 0, stream, ub, rows, bfront, j.b_pstride, c->d_cb, d_cb16,
                                d_cbc, (const unsigned int*)c->d_part, (int)nscan, c->d_alpha + 64, per, (int)npad, zH, j.h_elem_bytes, zP, j.p_elem_bytes,
                                cols + 1, rows + 1, skip_row0 ? 1 : 0, j.zero_key ? j.d_keys : nullptr);
-            prepped = true;
         };
         p.bcode = d_cbc;
         p.atab = c->d_alpha + 64;
@@ -390,31 +434,13 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         const unsigned char* cbp = c->d_cb;
         bool launched = false;
         c->last_strips2 = 0; c->last_scouts = 0; c->last_xcd_mode = 0;
-        // Two matrix columns per lane (sw_systolic2.inc): half as many strips -- and row segments of 504 bytes per store -- for the
-        // same work: 16384^2 +4 %, 8192^2 +11 %, 24576^2 +29 %, 32768^2 +32 %, 65536^2 +9 % over one column per lane.  Whole
-        // matrix of one pair, int32 H and P both stored, rows a multiple of 16; the alphabet (found on the device) must allow the
-        // perm path -- so both kernels are enqueued and each checks for itself which of them has to work.  (debug bit 14: off)
-        // Also: int8 P, either matrix left out, and band-resident launches (halo row in, last row out as granules).
-        const bool base_mode = j.d_H && j.d_P && j.h_elem_bytes == 4 && j.p_elem_bytes == 4 && !j.d_top && !j.d_top_gran && !j.d_bot_gran;   // int32 H + P, whole matrix
-        // Where it pays: always for int32 H + P (8-byte stores of both matrices); in the other output formats while the strip chain
-        // (~3.1 us per 63-column strip) rather than the output volume (~3.2 TB/s) bounds the fill -- measured: 262144 x 32768 with
-        // int8 P +18 %, 131072^2 with int8 P -3 %, 262144^2 P-only -21 % (two byte stores per row and the in-block arg-max).
-        const double est_chain = (double)S * 3.1e-6;
-        const double est_hbm = (double)(cols + 1) * (double)(rows + 1) * ((j.d_H ? (double)j.h_elem_bytes : 0.0) + (j.d_P ? (double)j.p_elem_bytes : 0.0)) / 3.2e12;
-        const bool pays = (j.d_H && j.d_P && j.p_elem_bytes == 4) || (j.d_H && j.h_elem_bytes == 8) || est_chain >= (j.d_H ? 0.5 : 2.0) * est_hbm || (c->opt_debug & 32768);
-        const bool two_cols = pays && perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 &&
-                              !j.d_left && !j.d_right && j.stride == cols + 1 && (rows % 16 == 0 || !j.d_bot_gran) && rows >= 1 && cols >= 1 &&   // (a band's last row leaves from a full block)
-                             
-                              (base_mode || (cols % 2 == 0)) &&   // (an odd column count leaves one lane with a single column: only the base mode handles it)
-                              !(c->opt_debug & (2 | 8 | 64 | 128 | 512 | 16384));
         if (two_cols) {
             const int64_t S2 = (cols + 125) / 126;
             swk::FillParams p2 = p;
             p2.nstrips = (int)S2;
             p2.h_bytes = j.h_elem_bytes;
-            int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, swk::sw_systolic2<6>, 768, 0));
-            if (per_cu >= 1) {
+            const int per_cu = per_cu2;
+            {
                 int grid2 = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S2, maxb), (int64_t)per_cu * c->num_cus));
                 // Scouts (sw_systolic2.inc): while every strip has a workgroup of its own and half as many more fit the device, the chain
                 // of strips runs in extra workgroups that keep nothing but the edge columns, and the workgroups that write the matrices
@@ -459,9 +485,14 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 p2.filler_bw_gbs = (int)c->opt_filler_bw_gbs;
                 c->last_xcd_mode = p2.xcd_mode;
                 c->last_scouts = p2.nscout;
-                // row 0 and column 0 are not the kernel's: zeros, except a band's halo row (its H comes from the row above, written by
-                // the kernel; its P belongs to the band above)
-                prepare(j.d_H, j.d_P, j.d_top || j.d_top_gran);
+                // one launch per fill: the kernel's prologue prepares (letter codes, every workgroup's padded copy of b, zeros in row 0 /
+                // column 0 -- except a band's halo row: its H comes from the row above, written by the kernel; its P belongs to the band
+                // above), its last workgroup out reports and re-arms key / abort flag / sync words -- which therefore are zero here, unless
+                // another kind of launch has used the key since
+                if (c->key_dirty) { HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream)); c->key_dirty = false; }
+                p2.sync = c->d_sync; p2.priv = c->d_priv; p2.priv_stride = priv_stride;
+                p2.bpad16_w = d_cb16; p2.bpad8_w = c->d_cb; p2.bcode_w = d_cbc; p2.atab_w = c->d_alpha + 64;
+                p2.result = j.d_result; p2.skip_row0 = (j.d_top || j.d_top_gran) ? 1 : 0;
                 // consumer waves (+ 9 - nc2 importers).  Behind scouts a filler is never the one a hand-off waits for: two importers do, and seven
                 // consumers keep more stores in flight (16384^2 -1.5 %, 12288^2 -2.5 %, 20480^2 +-0 against five)
                 const int nc2 = c->opt_consumers == 0 ? (scouts ? 7 : (chain_bound ? 5 : 6)) : (int)std::min<int64_t>(7, c->opt_consumers);
@@ -469,11 +500,14 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 else if (nc2 == 6) hipLaunchKernelGGL(swk::sw_systolic2<6>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
                 else if (nc2 == 5) hipLaunchKernelGGL(swk::sw_systolic2<5>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
                 else hipLaunchKernelGGL(swk::sw_systolic2<4>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
+                // the fall-back (an alphabet of more than 7 letters, known on the device only): enqueued behind, leaves at once otherwise
                 p.skip_if_perm = 1;
+                p.sync = c->d_sync; p.atab_w = c->d_alpha + 64; p.result = j.d_result;
                 c->last_strips2 = S2;
+                c->last_fused = true;
             }
         }
-        if (!prepped) prepare(nullptr, nullptr, false);
+        if (!two_cols) { prepare(nullptr, nullptr, false); c->key_dirty = true; }
 #define SW_LAUNCH(ns, nc)                                                                                                        \
     if (!launched && NS == ns && NC == nc) {                                                                                      \
         launched = true;                                                                                                          \
@@ -492,6 +526,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
 #undef SW_LAUNCH
         if (!launched) { set_err("unsupported strips_per_group/consumers combination %d/%d", NS, NC); return SW_EINVAL; }
     } else {
+        c->key_dirty = true;
         const int wpb = (int)c->opt_waves_per_block;
         const int64_t maxb = c->opt_max_blocks > 0 ? c->opt_max_blocks : 2ll * c->num_cus;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((S + wpb - 1) / wpb, maxb));
@@ -524,8 +559,10 @@ static int fill_one(sw_ctx* c, const sw_scores* scores, FillJob j, int64_t gcols
     DevOrder order(c, stream, j.concurrent);
     if (order.rc) return order.rc;
     j.d_keys = c->d_key;
-    j.zero_key = c->opt_engine == 0 && cols > 0 && rows > 0;   // (the systolic engine's preparation kernel zeroes the key and the abort flag)
-    if (!j.zero_key) HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream));
+    j.d_result = d_result;
+    j.zero_key = c->opt_engine == 0 && cols > 0 && rows > 0;   // (the systolic engine's preparation zeroes the key and the abort flag -- or finds them zero)
+    if (!j.zero_key) { HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream)); c->key_dirty = true; }
+    c->last_fused = false;
     if (cols == 0 || rows == 0) {
         // no interior cell: H (= halo row / zero column) and P are all boundary
         if (j.stride != cols + 1 || j.d_left || j.d_right || j.d_top_gran || j.d_bot_gran) { set_err("%s: empty tiles / bands are not supported", who); return SW_EINVAL; }
@@ -537,7 +574,8 @@ static int fill_one(sw_ctx* c, const sw_scores* scores, FillJob j, int64_t gcols
     } else {
         if (int rc = launch_fill(c, sc, j, stream)) return rc;
     }
-    hipLaunchKernelGGL(swk::sw_finalize, dim3(1), dim3(64), 0, stream, c->d_key, (const unsigned int*)(c->d_key + 1), d_result, 1);
+    // (a one-launch fill has written the result by itself: sw_systolic2.inc)
+    if (!c->last_fused) hipLaunchKernelGGL(swk::sw_finalize, dim3(1), dim3(64), 0, stream, c->d_key, (const unsigned int*)(c->d_key + 1), d_result, 1);
     HIP_TRY(hipGetLastError());
     return SW_OK;
 }
@@ -633,8 +671,9 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
     const int64_t cells = (cols + 1) * (rows + 1);
     for (int64_t k0 = 0; k0 < npairs; k0 += chunk) {
         const int64_t n = std::min(chunk, npairs - k0);
-        hipLaunchKernelGGL(swk::sw_batch_codes, dim3((unsigned)std::min<int64_t>((per + 255) / 256, 64), (unsigned)n), dim3(256), 0, stream, ub + k0 * b_stride, rows,
-                           b_stride, c->d_bcodes, per, front, (const unsigned int*)c->d_part, 1, c->d_alpha + 64);
+        hipLaunchKernelGGL(swk::sw_batch_codes, dim3((unsigned)std::min<int64_t>((per + 255) / 256, 64), (unsigned)std::min<int64_t>(n, 65535)), dim3(256), 0, stream,
+                           ub + k0 * b_stride, rows, b_stride, c->d_bcodes, per, front, (const unsigned int*)c->d_part, 1, c->d_alpha + 64, n);
+        HIP_TRY(hipGetLastError());
         if (k0 == 0) {   // the letter count (4 bytes) decides the path: the one host round trip of a batch call
             unsigned int nletters = 0;
             HIP_TRY(hipMemcpyAsync(&nletters, c->d_alpha + 64 + 256, 4, hipMemcpyDeviceToHost, stream));
@@ -673,12 +712,13 @@ int sw_fill_band_reserve(sw_ctx* c, int64_t cols, int64_t rows, int64_t total_ro
                          void* stream_) {
     const sw_scores* sc = scores ? scores : &kDefaultScores;
     if (!c || cols <= 0 || rows <= 0) { set_err("sw_fill_band_reserve: bad argument"); return SW_EINVAL; }
+    if (c->opt_engine != 0) { set_err("sw_fill_band_reserve needs the systolic engine"); return SW_EINVAL; }   // (no placeholder pointer may reach a launch)
     if (int rc = check_dims(cols, rows, sc, cols, total_rows)) return rc;
     HIP_TRY(hipSetDevice(c->device));
     FillJob j = make_job((const char*)16, cols, (const char*)16, rows, want_h ? (void*)16 : nullptr, h_elem_bytes, (void*)16, p_elem_bytes, cols + 1, nullptr, nullptr, nullptr);
     j.d_top_gran = (const unsigned long long*)16; j.d_bot_gran = (unsigned long long*)16;   // (placeholders: only their presence matters)
     j.top_tag = j.bot_tag = 1; j.total_rows = total_rows; j.concurrent = true; j.reserve_only = true;
-    j.d_keys = c->d_key;
+    j.d_keys = c->d_key; j.d_result = (sw_result*)16;
     std::unique_lock<std::mutex> lk(g_dev[c->device & 63].mu);
     return launch_fill(c, sc, j, (hipStream_t)stream_);
 }
@@ -713,6 +753,7 @@ int sw_batch_device_ex(sw_ctx* c, const char* d_a, int64_t a_stride, int64_t col
         if (hipMalloc((void**)&c->d_keys, c->keys_cap * 8) != hipSuccess) { c->d_keys = nullptr; c->keys_cap = 0; set_err("workspace allocation failed"); return SW_ENOMEM; }
     }
     HIP_TRY(hipMemsetAsync(c->d_key, 0, 16, stream));
+    c->key_dirty = true;
     const int64_t cells = (cols + 1) * (rows + 1);
     for (int64_t k0 = 0; k0 < npairs; k0 += chunk_max) {
         const int64_t n = std::min(chunk_max, npairs - k0);
@@ -747,10 +788,10 @@ int sw_batch_traceback_device(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t co
     const dim3 grid((unsigned)npairs), block(64);   // one wave per pair (csrc/sw_traceback.hip)
     if (p_elem_bytes == 4)
         hipLaunchKernelGGL(swk::sw_traceback_wave<int32_t>, grid, block, 0, (hipStream_t)stream_, (int32_t*)d_P, cols + 1, rows + 1, cells, (int64_t)-1, d_paths,
-                           d_paths ? path_cap : 0, d_results, (int64_t*)nullptr);
+                           d_paths ? path_cap : 0, d_results, (int64_t*)nullptr, (unsigned int*)nullptr);
     else
         hipLaunchKernelGGL(swk::sw_traceback_wave<signed char>, grid, block, 0, (hipStream_t)stream_, (signed char*)d_P, cols + 1, rows + 1, cells, (int64_t)-1,
-                           d_paths, d_paths ? path_cap : 0, d_results, (int64_t*)nullptr);
+                           d_paths, d_paths ? path_cap : 0, d_results, (int64_t*)nullptr, (unsigned int*)nullptr);
     HIP_TRY(hipGetLastError());
     return SW_OK;
 }
@@ -806,15 +847,19 @@ int sw_align_auto(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t
 }
 
 static int traceback_launch(sw_ctx* c, void* d_P, int p_elem_bytes, int64_t cols, int64_t rows, int64_t max_pos, int64_t* d_path, int64_t path_cap,
-                            sw_result* d_result, int64_t* d_stop, hipStream_t stream) {
+                            sw_result* d_result, int64_t* d_stop, hipStream_t stream, unsigned int* d_pathbits = nullptr) {
     // a big matrix is in no cache when the walk starts: a second wave reads ahead of the walking one (csrc/sw_traceback.hip)
-    const dim3 block((double)(cols + 1) * (double)(rows + 1) * p_elem_bytes > 64.0e6 ? 128 : 64);
-    if (p_elem_bytes == 4)
+    // (p_elem_bytes 0: a 2-bit matrix, four cells per byte)
+    const dim3 block((double)(cols + 1) * (double)(rows + 1) * (p_elem_bytes ? (double)p_elem_bytes : 0.25) > 64.0e6 ? 128 : 64);
+    if (p_elem_bytes == 0)
+        hipLaunchKernelGGL(swk::sw_traceback_wave<swk::P2Cells>, dim3(1), block, 0, stream, (swk::P2Cells*)d_P, cols + 1, rows + 1, (int64_t)0, max_pos, d_path,
+                           d_path ? path_cap : 0, d_result, d_stop, d_pathbits);
+    else if (p_elem_bytes == 4)
         hipLaunchKernelGGL(swk::sw_traceback_wave<int32_t>, dim3(1), block, 0, stream, (int32_t*)d_P, cols + 1, rows + 1, (int64_t)0, max_pos, d_path,
-                           d_path ? path_cap : 0, d_result, d_stop);
+                           d_path ? path_cap : 0, d_result, d_stop, (unsigned int*)nullptr);
     else
         hipLaunchKernelGGL(swk::sw_traceback_wave<signed char>, dim3(1), block, 0, stream, (signed char*)d_P, cols + 1, rows + 1, (int64_t)0, max_pos, d_path,
-                           d_path ? path_cap : 0, d_result, d_stop);
+                           d_path ? path_cap : 0, d_result, d_stop, (unsigned int*)nullptr);
     HIP_TRY(hipGetLastError());
     return SW_OK;
 }
@@ -866,7 +911,6 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
     if (hipMalloc((void**)&d_res, sizeof(sw_result)) != hipSuccess) { set_err("sw_alloc_outputs: allocation failed"); return SW_ENOMEM; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    size_t spacer_total = 0;
     int best = -1, rc = SW_OK;
     for (int i = 0; i < trials; ++i) {
         Cand k = {nullptr, nullptr, nullptr, nullptr, 0.f};
@@ -889,8 +933,7 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < sp + pbytes + (8ull << 30)) sp = 0;   // not enough head room: plain candidate
         }
-        if (sp && hipMalloc(&k.spacer, sp) == hipSuccess) spacer_total += sp;
-        else { (void)hipGetLastError(); k.spacer = nullptr; }
+        if (!sp || hipMalloc(&k.spacer, sp) != hipSuccess) { (void)hipGetLastError(); k.spacer = nullptr; }
         if (hipMalloc(&k.Pbase, pbytes + phase) != hipSuccess) { (void)hipGetLastError(); if (k.spacer) (void)hipFree(k.spacer); break; }
         // P two MiB out of phase with H modulo 4 MiB
         const uintptr_t want = ((uintptr_t)k.H + (2u << 20)) % phase;
@@ -985,6 +1028,36 @@ int sw_p8_to_p32_device(sw_ctx* c, const void* d_P8, int32_t* d_P32, int64_t cou
     hipLaunchKernelGGL(swk::sw_widen_p8, dim3(nb), dim3(256), 0, (hipStream_t)stream_, (const signed char*)d_P8, d_P32, (size_t)count);
     HIP_TRY(hipGetLastError());
     return SW_OK;
+}
+
+// ---- 2-bit predecessor matrix: 4 codes per byte + a path bitmap; csrc/sw_kernels.hip, csrc/sw_traceback.hip
+int sw_p_to_p2_device(sw_ctx* c, const void* d_P, int p_elem_bytes, void* d_P2, uint32_t* d_pathbits, int64_t count, void* stream_) {
+    if (!c || count < 0 || (count > 0 && (!d_P || !d_P2)) || (p_elem_bytes != 1 && p_elem_bytes != 4)) { set_err("sw_p_to_p2_device: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (count == 0) return SW_OK;
+    const unsigned nb = (unsigned)std::min<int64_t>(((count + 31) / 32 + 255) / 256, 16384);
+    if (p_elem_bytes == 1) hipLaunchKernelGGL(swk::sw_pack_p2<signed char>, dim3(nb), dim3(256), 0, (hipStream_t)stream_, (const signed char*)d_P, (unsigned char*)d_P2, d_pathbits, (size_t)count);
+    else hipLaunchKernelGGL(swk::sw_pack_p2<int32_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream_, (const int32_t*)d_P, (unsigned char*)d_P2, d_pathbits, (size_t)count);
+    HIP_TRY(hipGetLastError());
+    return SW_OK;
+}
+int sw_p2_to_p32_device(sw_ctx* c, const void* d_P2, const uint32_t* d_pathbits, int32_t* d_P32, int64_t count, void* stream_) {
+    if (!c || count < 0 || (count > 0 && (!d_P2 || !d_P32))) { set_err("sw_p2_to_p32_device: bad argument"); return SW_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (count == 0) return SW_OK;
+    const unsigned nb = (unsigned)std::min<int64_t>(((count + 3) / 4 + 255) / 256, 16384);
+    hipLaunchKernelGGL(swk::sw_unpack_p2, dim3(nb), dim3(256), 0, (hipStream_t)stream_, (const unsigned char*)d_P2, d_pathbits, d_P32, (size_t)count);
+    HIP_TRY(hipGetLastError());
+    return SW_OK;
+}
+int sw_traceback_p2_device(sw_ctx* c, const void* d_P2, int64_t cols, int64_t rows, int64_t max_pos, uint32_t* d_pathbits, int64_t* d_path,
+                           int64_t path_cap, sw_result* d_result, void* stream_) {
+    if (!c || !d_P2 || !d_result || cols < 0 || rows < 0 || max_pos < 0 || max_pos >= (cols + 1) * (rows + 1)) {
+        set_err("sw_traceback_p2_device: bad argument");
+        return SW_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    return traceback_launch(c, const_cast<void*>(d_P2), 0, cols, rows, max_pos, d_path, path_cap, d_result, nullptr, (hipStream_t)stream_, d_pathbits);
 }
 
 int sw_row_checksums_device(sw_ctx* c, const void* d_X, int elem_bytes, int64_t rows1, int64_t m, uint64_t* d_cs,

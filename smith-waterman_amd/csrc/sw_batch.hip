@@ -33,7 +33,8 @@ constexpr u32 SB_OOB = 0xFFFFFF00u;
 // bcode[pair * per + front + i] = code(b[i]); 0x0D outside the sequence -- as a v_perm_b32 selector byte that yields 0xFF, the
 // score -1 of a cell outside the matrix.  Block (0,0) publishes the code table (atab[0..255], letter count at atab[256]).
 __global__ void __launch_bounds__(256) sw_batch_codes(const unsigned char* __restrict__ b, int64_t rows, int64_t b_pstride, unsigned char* __restrict__ bcode,
-                                                      int64_t per, int front, const unsigned int* __restrict__ part, int npart, unsigned char* __restrict__ atab) {
+                                                      int64_t per, int front, const unsigned int* __restrict__ part, int npart, unsigned char* __restrict__ atab,
+                                                      int64_t npairs) {
     __shared__ unsigned char tab[256];
     __shared__ unsigned int present[8];
     {
@@ -60,11 +61,12 @@ __global__ void __launch_bounds__(256) sw_batch_codes(const unsigned char* __res
         }
     }
     __syncthreads();
-    const int64_t pair = blockIdx.y;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
-        const bool in = (i >= front && i - front < rows);
-        bcode[pair * per + i] = in ? tab[b[pair * b_pstride + i - front]] : (unsigned char)0x0D;
-    }
+    // (gridDim.y is capped at 65535 by the host -- the limit a HIP runtime may enforce: the pairs are taken grid-stride)
+    for (int64_t pair = blockIdx.y; pair < npairs; pair += gridDim.y)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.x * blockDim.x) {
+            const bool in = (i >= front && i - front < rows);
+            bcode[pair * per + i] = in ? tab[b[pair * b_pstride + i - front]] : (unsigned char)0x0D;
+        }
 }
 
 __device__ __forceinline__ int sb_dpp_shr1(int old, int src) {   // lane l <- lane l-1; lane 0 keeps `old`

@@ -58,6 +58,15 @@ struct FillParams {
     int nscout;                          // sw_systolic2: workgroups 0..nscout-1 only run the chain (two strips each) and leave the edge columns to the others
     int filler_hop_ps, filler_tau_ps, filler_bw_gbs;    // sw_systolic2 behind scouts: pacing of the fillers (sw_systolic2.inc), 0 = none
     int xcd_mode;                        // sw_systolic2: 256 workgroups, roles dealt per XCD (workgroup i on XCD i % 8; nscout = scout workgroups in all)
+    // one launch per fill (round 4): the preparation and the finalisation of a fill are the prologue / epilogue of sw_systolic2 itself
+    unsigned int* sync;                  // per context, all zero between launches: [0] arrivals at the prologue's grid barrier, [1] workgroups that have
+                                         // left, [2] the letter count the prologue found (kept for the fall-back kernel), [8..15] presence map of the byte values
+    unsigned char* priv;                 // per workgroup: a zero-padded copy of b and its letter codes ([bpad8 | bcode], bpad_pstride bytes each)
+    int64_t priv_stride;                 // bytes between two workgroups' copies
+    unsigned short* bpad16_w;            // writable views of the shared padded copies (the prologue of workgroup 0 fills them when the fall-back kernel has to run)
+    unsigned char* bpad8_w; unsigned char* bcode_w; unsigned char* atab_w;
+    sw_result* result;                   // != NULL: the last workgroup to leave writes the result and re-arms key / abort flag / sync for the next launch
+    int skip_row0;                       // prologue: row 0 of H / P is not this launch's to clear (a band's halo row)
 };
 constexpr int SW_XTAB_OFF = 448;         // atab + 448: unsigned int[256], XCD + 1 of every workgroup of the running sw_systolic2 launch (0: not there yet)
 constexpr int SW_PERM_PAD = -100;        // score of any cell outside the sequences (perm producer)
@@ -76,7 +85,7 @@ struct BatchParams {
     int debug;                       // bit 0: drop the H / P stores (timing experiments only)
 };
 __global__ void sw_batch_codes(const unsigned char* b, int64_t rows, int64_t b_pstride, unsigned char* bcode, int64_t per, int front,
-                               const unsigned int* part, int npart, unsigned char* atab);
+                               const unsigned int* part, int npart, unsigned char* atab, int64_t npairs);
 template <int C, int PB>
 __global__ void sw_batch_wave(BatchParams p);
 
@@ -97,8 +106,12 @@ __global__ void sw_prep_reduce(unsigned int* part, int npart);
 __global__ void sw_finalize(const unsigned long long* key, const unsigned int* abort_flag, sw_result* res, int n);
 template <typename PT>
 __global__ void sw_traceback_wave(PT* P, int64_t M, int64_t rows1, int64_t pstride, int64_t start_pos, int64_t* paths, int64_t cap, sw_result* res,
-                                  int64_t* stop);
+                                  int64_t* stop, unsigned int* pathbits);
 template <typename T> __global__ void sw_row_checksums(const T* X, int64_t m, unsigned long long* cs);
 __global__ void sw_widen_p8(const signed char* P8, int32_t* P32, size_t n);
+// 2-bit predecessor matrix (4 codes per byte) + path bitmap (1 bit per cell): sw_kernels.hip, sw_traceback.hip
+struct P2Cells { unsigned char v; };     // tag type: sw_traceback_wave<P2Cells> walks a packed matrix
+template <typename PT> __global__ void sw_pack_p2(const PT* P, unsigned char* P2, unsigned int* bits, size_t n);
+__global__ void sw_unpack_p2(const unsigned char* P2, const unsigned int* bits, int32_t* P32, size_t n);
 
 }  // namespace swk

@@ -287,6 +287,59 @@ __global__ void sw_widen_p8(const signed char* __restrict__ P8, int32_t* __restr
     }
 }
 
+// ---- 2-bit predecessor matrix: 4 codes per byte, cell k in bits 2 (k & 3) .. 2 (k & 3) + 1 of byte k >> 2.  Two bits
+// cannot hold the sign the traceback leaves on a path (P *= PATH, serial_smithW.c:271), so a traced path is a bitmap beside it:
+// bit k & 31 of word k >> 5.  One thread per 32 cells: 8 bytes of codes + one bitmap word.
+template <typename PT>
+__global__ void __launch_bounds__(256) sw_pack_p2(const PT* __restrict__ P, unsigned char* __restrict__ P2, unsigned int* __restrict__ bits, size_t n) {
+    const size_t nw = (n + 31) / 32, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += stride) {
+        const size_t k0 = w * 32;
+        u64 codes = 0;
+        unsigned int neg = 0;
+        if (sizeof(PT) == 1 && k0 + 32 <= n && (((uintptr_t)(P + k0)) & 15) == 0) {
+            const int4 v0 = *(const int4*)(P + k0), v1 = *(const int4*)(P + k0 + 16);
+            const int wv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const int c = (int)(signed char)(wv[q >> 2] >> (8 * (q & 3)));
+                codes |= (u64)(unsigned)((c < 0 ? -c : c) & 3) << (2 * q);
+                neg |= (c < 0 ? 1u : 0u) << q;
+            }
+        } else {
+#pragma unroll 8
+            for (int q = 0; q < 32; ++q) {
+                const int c = (k0 + q < n) ? (int)P[k0 + q] : 0;
+                codes |= (u64)(unsigned)((c < 0 ? -c : c) & 3) << (2 * q);
+                neg |= (c < 0 ? 1u : 0u) << q;
+            }
+        }
+        *(u64*)(P2 + w * 8) = codes;
+        if (bits) bits[w] = neg;
+    }
+}
+template __global__ void sw_pack_p2<signed char>(const signed char*, unsigned char*, unsigned int*, size_t);
+template __global__ void sw_pack_p2<int32_t>(const int32_t*, unsigned char*, unsigned int*, size_t);
+
+// back to the reference's int32 layout: P32[k] = code, negated where the bitmap marks the path.  One thread per byte (4 cells, 16 bytes out).
+__global__ void __launch_bounds__(256) sw_unpack_p2(const unsigned char* __restrict__ P2, const unsigned int* __restrict__ bits, int32_t* __restrict__ P32, size_t n) {
+    const size_t nb = (n + 3) / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += stride) {
+        const unsigned v = P2[b];
+        const unsigned m = bits ? (bits[b >> 3] >> (4 * (b & 7))) & 15u : 0u;
+        int c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int code = (int)((v >> (2 * q)) & 3u);
+            c[q] = ((m >> q) & 1u) ? -code : code;
+        }
+        const size_t k = b * 4;
+        if (k + 4 <= n && (((uintptr_t)(P32 + k)) & 15) == 0) *(int4*)(P32 + k) = make_int4(c[0], c[1], c[2], c[3]);
+        else
+            for (int q = 0; q < 4 && k + q < n; ++q) P32[k + q] = c[q];
+    }
+}
+
 // cs[i] = sum_j (u64)(u32)X[i][j] * ((j+1) * 0x9E3779B97F4A7C15); one block per row
 template <typename T>
 __global__ void __launch_bounds__(256) sw_row_checksums(const T* __restrict__ X, int64_t m, u64* __restrict__ cs) {

@@ -117,7 +117,15 @@ int sw_multi_create(const int* devices, int ndev, const char* a, int64_t cols, c
         for (int k = 0; k < nb; ++k) share0 += (m->bands[k].device == bd.device);
         bd.host_gran = share0 > 1;
         auto gran_alloc = [&](uint64_t** p) {
-            if (!bd.host_gran) return dev_alloc((void**)p, (size_t)(cols + 1) * 8);
+            // Distinct GPUs: the granules are written by a PEER (hipMemcpyPeerAsync over xGMI) while this GPU's kernel polls them.  A peer's
+            // write does not pass through this GPU's L2, so the buffer must be fine-grained memory -- never cached there; ordinary
+            // (coarse-grained) device memory is only guaranteed coherent with other agents at kernel boundaries.  The polling load
+            // (s2_load_top / the importers of sw_systolic: system scope, sc0 sc1) then always goes to memory.
+            if (!bd.host_gran) {
+                if (hipExtMallocWithFlags((void**)p, (size_t)(cols + 1) * 8, hipDeviceMallocFinegrained) == hipSuccess) return true;
+                (void)hipGetLastError();
+                return dev_alloc((void**)p, (size_t)(cols + 1) * 8);
+            }
             if (hipHostMalloc((void**)p, (size_t)(cols + 1) * 8, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) return false;
             memset(*p, 0, (size_t)(cols + 1) * 8);
             return true;
@@ -185,8 +193,11 @@ int sw_multi_fill(sw_multi* m, const sw_scores* scores, int nchunks, sw_result* 
         HIP_TRYM(hipSetDevice(bd.device));
         int share = 0;
         for (int k = 0; k < nb; ++k) share += (m->bands[k].device == bd.device);
+        // a band with a GPU of its own leaves a few CUs free: a peer copy normally runs on the SDMA engines, but where the runtime falls
+        // back to a blit kernel that kernel needs a CU beside the resident band kernel (multi.py reserves the same 16 for RCCL's kernels)
+        const int reserve = (share == 1 && nb > 1) ? 16 : 0;
         const int rc = sw_fill_band_device(bd.ctx, bd.d_a, cols, bd.d_b, bd.hi - bd.lo, m->rows, scores, bd.d_H, 4, bd.d_P, m->p_elem_bytes,
-                                           bd.d_top, bd.d_top ? tag : 0, bd.d_bot, bd.d_bot ? tag : 0, bd.h_done, 0, share > 1, bd.d_res, bd.stream);
+                                           bd.d_top, bd.d_top ? tag : 0, bd.d_bot, bd.d_bot ? tag : 0, bd.h_done, reserve, share > 1, bd.d_res, bd.stream);
         if (rc != SW_OK) {   // bands already launched would wait for a halo that never comes: they give up after "band_wait_ms"
             for (int k = 0; k < g; ++k) { (void)hipSetDevice(m->bands[k].device); (void)hipStreamSynchronize(m->bands[k].stream); }
             return rc;
@@ -311,6 +322,63 @@ int sw_multi_band_info(sw_multi* m, int g, int* device, int64_t* row_lo, int64_t
     if (d_H) *d_H = bd.d_H;
     if (d_P) *d_P = bd.d_P;
     return SW_OK;
+}
+
+// Adaptive dispatch with all three executors of omp_smithW-v7-adaptive.cpp:304-396 (serial / OpenMP threads / offload, chosen there per
+// anti-diagonal by its length): here the whole problem is sized once --
+//   0  the host fill (sw_fill_cpu) below ~2e5 cells: launch + transfer latency would dominate;
+//   1  ONE GPU (ctx, or devices[0]) while a single pair is bound by its strip chain, which more GPUs do not shorten;
+//   2  row bands over ALL the given devices (sw_multi_*) from multi_min_cells cells on (0: 4e9, about 65536^2, where a fill is
+//      bound by the HBM stores of one GPU), or whenever H + P do not fit the first device.
+// H, P, max_pos, max_score and path_len come back exactly as serial_smithW leaves them (the traceback runs on the host P).
+int sw_align_auto_multi(sw_ctx* ctx, const int* devices, int ndev, const char* a, int64_t cols, const char* b, int64_t rows, const sw_scores* scores,
+                        int32_t* H, int32_t* P, sw_result* result, int* executor, int64_t multi_min_cells) {
+    if (!result || !H || !P || cols < 0 || rows < 0 || ndev < 0 || (ndev > 0 && !devices)) { set_err("sw_align_auto_multi: bad argument"); return SW_EINVAL; }
+    const double cells = (double)cols * (double)rows;
+    int ex = 0;
+    if ((ctx || ndev > 0) && cells >= 2.0e5) {
+        ex = 1;
+        if (ndev >= 2 && rows >= 16 * (int64_t)ndev) {
+            if (cells >= (multi_min_cells > 0 ? (double)multi_min_cells : 4.0e9)) ex = 2;
+            else {
+                size_t fr = 0, tot = 0;
+                if (hipSetDevice(devices[0]) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess && (double)(cols + 1) * (double)(rows + 1) * 8.0 > 0.9 * (double)fr) ex = 2;
+                else (void)hipGetLastError();
+            }
+        }
+    }
+    if (executor) *executor = ex;
+    if (ex < 2) {
+        sw_ctx* c = ex == 1 ? ctx : nullptr;
+        sw_ctx* own = nullptr;
+        if (ex == 1 && !c) {
+            if (int rc = sw_create(devices[0], &own)) return rc;
+            c = own;
+        }
+        const int rc = sw_align_auto(c, a, cols, b, rows, scores, H, P, result, nullptr);
+        if (own) sw_destroy(own);
+        return rc;
+    }
+    sw_multi* m = nullptr;
+    if (int rc = sw_multi_create(devices, ndev, a, cols, b, rows, 4, 1, &m)) return rc;
+    int rc = sw_multi_fill(m, scores, 0, result);
+    const size_t M = (size_t)cols + 1;
+    memset(H, 0, M * 4); memset(P, 0, M * 4);                       // row 0 (serial_smithW.c:96-103: calloc)
+    for (size_t g = 0; g < m->bands.size() && rc == SW_OK; ++g) {   // band-local row 0 is the halo row: rows lo+1 .. hi are rows 1 .. of the band
+        const sw_multi_band& bd = m->bands[g];
+        const size_t n = (size_t)(bd.hi - bd.lo) * M * 4;
+        if (hipSetDevice(bd.device) != hipSuccess || hipMemcpy(H + (size_t)(bd.lo + 1) * M, (const int32_t*)bd.d_H + M, n, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(P + (size_t)(bd.lo + 1) * M, (const int32_t*)bd.d_P + M, n, hipMemcpyDeviceToHost) != hipSuccess) {
+            set_err("sw_align_auto_multi: copying band %zu back failed", g);
+            rc = SW_EDEVICE;
+        }
+    }
+    sw_multi_free(m);
+    if (rc != SW_OK) return rc;
+    int64_t n = 0;
+    rc = sw_traceback_host(P, cols, rows, result->max_pos, nullptr, 0, &n);
+    result->path_len = n;
+    return rc;
 }
 
 int sw_multi_nbands(sw_multi* m) { return m ? (int)m->bands.size() : 0; }

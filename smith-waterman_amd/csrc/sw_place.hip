@@ -1,0 +1,70 @@
+// sw_place.hip -- placement of the output matrices in HBM: probe kernel + helpers.
+//
+// Where the driver maps H and P in physical memory moves a store-bound fill by 25-35 %: physical HBM falls into a few coarse
+// "classes" (regions of several GiB), and two store streams that go to the SAME class at the same time are slower than two
+// streams into different classes.  sw_two_stream_probe reproduces the fill's store pattern -- one row segment per workgroup and
+// row, the H and the P segment of a row back to back -- on two arbitrary buffers, so that a pair can be classified in tens of
+// microseconds instead of with trial fills of the caller's problem.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sw_kernels.h"
+
+namespace swh { void set_err(const char* fmt, ...); }
+using swh::set_err;
+
+namespace swk {
+
+// grid: nseg * nrg workgroups of 256 threads; workgroup (seg, rg) stores `seg_dw2` 8-byte elements of every row r = rg, rg + nrg, ...
+// of X and (mode 0) of Y at byte offset r * pitch + seg * seg_dw2 * 8.  mode 1: X only; mode 2: X and X + half the rows (one buffer,
+// two streams).  Wave v of the workgroup takes every 4th of the workgroup's rows.
+__global__ void __launch_bounds__(256) sw_two_stream_probe(unsigned char* __restrict__ X, unsigned char* __restrict__ Y, int64_t rows, int64_t pitch,
+                                                           int seg_dw2, int nseg, int nrg, int mode, unsigned int val) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int seg = (int)blockIdx.x % nseg, rg = (int)blockIdx.x / nseg;
+    if (lane >= seg_dw2) return;
+    const int64_t col = ((int64_t)seg * seg_dw2 + lane) * 8;
+    const int64_t half = (rows / 2) * pitch;
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    const v2u v = {val, val + (unsigned)lane};
+    if (mode == 4) {   // two streams, write-back stores
+        for (int64_t r = rg + (int64_t)wave * nrg; r < rows; r += 4 * (int64_t)nrg) {
+            const int64_t o = r * pitch + col;
+            *(v2u*)(X + o) = v;
+            *(v2u*)(Y + o) = v;
+        }
+        return;
+    }
+    for (int64_t r = rg + (int64_t)wave * nrg; r < (mode == 2 ? rows / 2 : rows); r += 4 * (int64_t)nrg) {
+        const int64_t o = r * pitch + col;
+        __builtin_nontemporal_store(v, (v2u*)(X + o));
+        if (mode == 0) __builtin_nontemporal_store(v, (v2u*)(Y + o));
+        else if (mode == 2) __builtin_nontemporal_store(v, (v2u*)(X + half + o));
+    }
+}
+
+}  // namespace swk
+
+extern "C" {
+
+// (library-internal, experiments + the allocator) time `reps` launches of the probe on (d_X, d_Y): rows x pitch bytes each
+int sw_probe_streams(sw_ctx* c, void* d_X, void* d_Y, int64_t rows, int64_t pitch, int seg_dw2, int nrg, int mode, int reps, float* ms) {
+    if (!d_X || !ms || rows <= 0 || pitch <= 0 || seg_dw2 <= 0 || seg_dw2 > 64 || nrg <= 0 || reps <= 0) { set_err("sw_probe_streams: bad argument"); return SW_EINVAL; }
+    const int nseg = (int)(pitch / (seg_dw2 * 8));
+    if (nseg <= 0) { set_err("sw_probe_streams: bad argument"); return SW_EINVAL; }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return SW_EDEVICE;
+    hipLaunchKernelGGL(swk::sw_two_stream_probe, dim3(nseg * nrg), dim3(256), 0, nullptr, (unsigned char*)d_X, (unsigned char*)d_Y, rows, pitch, seg_dw2, nseg, nrg, mode, 1u);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(swk::sw_two_stream_probe, dim3(nseg * nrg), dim3(256), 0, nullptr, (unsigned char*)d_X, (unsigned char*)d_Y, rows, pitch, seg_dw2, nseg, nrg, mode, 2u + i);
+    (void)hipEventRecord(e1, nullptr);
+    const hipError_t e = hipEventSynchronize(e1);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (e != hipSuccess) { set_err("sw_probe_streams: %s", hipGetErrorString(e)); return SW_EDEVICE; }
+    *ms = t / reps;
+    return SW_OK;
+}
+
+}  // extern "C"

@@ -1047,9 +1047,10 @@ __device__ __forceinline__ int consumer_loop32(u32& z, u32& E, u32& bestv, u32& 
     return status;
 }
 
+// (the kernel proper: sw_systolic below, behind sw_systolic2.inc, wraps this body -- as the fall-back of a one-launch fill it also runs
+// that file's epilogue)
 template <typename HT, int NS, int NC>
-__global__ void __launch_bounds__(NS == 1 ? 768 : 64 * (NS * (1 + NC) + 2))   // NS == 1: 12 waves, SIMD 0 belongs to the producer (3 waves per SIMD: 168 VGPRs)
-sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsigned char* bpad, FillParams p) {
+__device__ __forceinline__ void sw_systolic_body(const unsigned char* seq_a, const unsigned char* seq_b, const unsigned char* bpad, FillParams p) {
     __shared__ SysLds<NS> lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1062,7 +1063,6 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
     // perm producer: eligible on the host side (score range -> gbias != 0) AND an alphabet of at most 7 letters (found on
     // the device by sw_pad_b); it always uses the fast step numbering
     const bool perm = (p.gbias != 0) && (*(const unsigned int*)(p.atab + 256) <= 7u) && !(p.debug_flags & 16);
-    if (perm && p.skip_if_perm) return;   // the two-column kernel (sw_systolic2.inc), launched right before this one, has done the fill
     const int phib = perm ? p.nstrips - 1 : p.phi_base;
     const int gb = perm ? (int)p.gbias : 0;       // carried by every G value
     const int ugran = perm ? 64 : SY_U;   // the perm producer tests for the end once per 64-step chunk
@@ -1767,18 +1767,6 @@ sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsign
     }
 }
 
-#define SW_INST(NS, NC)                                                                                                   \
-    template __global__ void sw_systolic<int32_t, NS, NC>(const unsigned char*, const unsigned char*, const unsigned char*, FillParams); \
-    template __global__ void sw_systolic<int64_t, NS, NC>(const unsigned char*, const unsigned char*, const unsigned char*, FillParams);
-SW_INST(2, 2)
-SW_INST(2, 3)
-SW_INST(2, 4)
-SW_INST(1, 2)
-SW_INST(1, 3)
-SW_INST(1, 4)
-SW_INST(1, 6)
-SW_INST(1, 7)
-#undef SW_INST
 
 // Wipe the self-tagged edge buffer with the SAME kind of store the producers use (agent-scope, written through): the
 // importers read it with agent-scope loads that are served from memory, and a plain memset's zeros can still sit in the
@@ -1907,5 +1895,27 @@ __global__ void __launch_bounds__(256) sw_prep_code(const unsigned char* __restr
 }
 
 #include "sw_systolic2.inc"
+
+template <typename HT, int NS, int NC>
+__global__ void __launch_bounds__(NS == 1 ? 768 : 64 * (NS * (1 + NC) + 2))   // NS == 1: 12 waves, SIMD 0 belongs to the producer (3 waves per SIMD: 168 VGPRs)
+sw_systolic(const unsigned char* seq_a, const unsigned char* seq_b, const unsigned char* bpad, FillParams p) {
+    // enqueued behind sw_systolic2 (skip_if_perm): that kernel has done the fill unless the alphabet (found on the device, by its prologue)
+    // has more than 7 letters -- then this one fills, from the shared padded copies workgroup 0 of that launch left, and reports like it
+    if (p.skip_if_perm && p.gbias != 0 && *(const unsigned int*)(p.atab + 256) <= 7u && !(p.debug_flags & 16)) return;
+    sw_systolic_body<HT, NS, NC>(seq_a, seq_b, bpad, p);
+    if (p.skip_if_perm && p.sync) s2_epilogue(p, true);
+}
+#define SW_INST(NS, NC)                                                                                                   \
+    template __global__ void sw_systolic<int32_t, NS, NC>(const unsigned char*, const unsigned char*, const unsigned char*, FillParams); \
+    template __global__ void sw_systolic<int64_t, NS, NC>(const unsigned char*, const unsigned char*, const unsigned char*, FillParams);
+SW_INST(2, 2)
+SW_INST(2, 3)
+SW_INST(2, 4)
+SW_INST(1, 2)
+SW_INST(1, 3)
+SW_INST(1, 4)
+SW_INST(1, 6)
+SW_INST(1, 7)
+#undef SW_INST
 
 }  // namespace swk

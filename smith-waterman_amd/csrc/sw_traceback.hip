@@ -9,6 +9,7 @@
 // edge, and the next window is anchored at the new cursor.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "sw_kernels.h"
 
 namespace swk {
@@ -46,6 +47,36 @@ __device__ __forceinline__ void tb_load_window(const PT* base, u32 num_records, 
     if constexpr (sizeof(PT) == 4) { TB_LOAD("buffer_load_dword"); } else { TB_LOAD("buffer_load_sbyte"); }
 #undef TB_LOAD
 #undef TB_LD4
+}
+
+// The same window out of a 2-bit matrix (P2Cells: 4 codes per byte, cell k in bits 2 (k & 3) of byte k >> 2): every lane fetches the byte
+// that holds its cell of row q (byte offset (cw + q M) >> 2 from the byte of the window's corner cell, cw = (corner & 3) + lane) and
+// shifts its code out.  One asm statement, like the loader above: the compiler never sees the window registers.  nbytes: bytes from the
+// corner's byte to the end of the matrix (beyond: 0, the buffer bounds check).
+__device__ __forceinline__ void tb_load_window_p2(const unsigned char* corner_byte, u32 corner_phase, u32 M, u32 nbytes, int lane) {
+    const uint64_t b = (uint64_t)(uintptr_t)corner_byte;
+    const int d0 = __builtin_amdgcn_readfirstlane((int)(u32)b), d1 = __builtin_amdgcn_readfirstlane((int)(u32)(b >> 32));
+    u32 cw = corner_phase + (u32)lane, cw2 = cw;
+#define TB_P2_LD(Q) "v_lshrrev_b32 v62, 2, %[cw]\n\tbuffer_load_ubyte v" #Q ", v62, s[76:79], 0 offen\n\tv_add_u32 %[cw], %[cw], %[m]\n\t"
+#define TB_P2_EX(Q) "v_and_b32 v62, 3, %[cw2]\n\tv_lshlrev_b32 v62, 1, v62\n\tv_lshrrev_b32 v" #Q ", v62, v" #Q "\n\tv_and_b32 v" #Q ", 3, v" #Q "\n\tv_add_u32 %[cw2], %[cw2], %[m]\n\t"
+#define TB_P2_8(X, A, B, C, D, E, F, G, H) X(A) X(B) X(C) X(D) X(E) X(F) X(G) X(H)
+#define TB_P2_ALL(X)                                                                                                          \
+    TB_P2_8(X, 64, 65, 66, 67, 68, 69, 70, 71) TB_P2_8(X, 72, 73, 74, 75, 76, 77, 78, 79) TB_P2_8(X, 80, 81, 82, 83, 84, 85, 86, 87)           \
+    TB_P2_8(X, 88, 89, 90, 91, 92, 93, 94, 95) TB_P2_8(X, 96, 97, 98, 99, 100, 101, 102, 103) TB_P2_8(X, 104, 105, 106, 107, 108, 109, 110, 111) \
+    TB_P2_8(X, 112, 113, 114, 115, 116, 117, 118, 119) TB_P2_8(X, 120, 121, 122, 123, 124, 125, 126, 127)
+    asm volatile(
+        "s_mov_b32 s76, %[d0]\n\ts_mov_b32 s77, %[d1]\n\ts_mov_b32 s78, %[nr]\n\ts_mov_b32 s79, 0x00020000\n\t"
+        "s_nop 4\n\t"
+        TB_P2_ALL(TB_P2_LD)
+        "s_waitcnt vmcnt(0)\n\t"
+        TB_P2_ALL(TB_P2_EX)
+        : [cw] "+v"(cw), [cw2] "+v"(cw2)
+        : [d0] "s"(d0), [d1] "s"(d1), [nr] "s"(nbytes), [m] "s"(M)
+        : "memory", "s76", "s77", "s78", "s79", "v62", TB_WINDOW_REGS);
+#undef TB_P2_ALL
+#undef TB_P2_8
+#undef TB_P2_EX
+#undef TB_P2_LD
 }
 
 // Up to 64 steps inside the window.  ti / tj: cursor (row register, lane); returns the number of steps taken, their codes in
@@ -134,7 +165,11 @@ __device__ __forceinline__ u32 tb_wave_prefix_sum(u32 v) {   // inclusive, 64 la
 // paths + k * cap and the index of the cell the walk stopped at (the first cell with P <= 0) to stop[k].
 template <typename PT>
 __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int64_t M, int64_t rows1, int64_t pstride, int64_t start_pos,
-                                                         int64_t* __restrict__ paths, int64_t cap, sw_result* __restrict__ res, int64_t* __restrict__ stop) {
+                                                         int64_t* __restrict__ paths, int64_t cap, sw_result* __restrict__ res, int64_t* __restrict__ stop,
+                                                         unsigned int* __restrict__ pathbits) {
+    // PACKED: a 2-bit matrix (4 codes per byte).  It cannot hold the sign the walk leaves on its cells: the path is marked in the
+    // bitmap `pathbits` instead (bit k & 31 of word k >> 5 for cell k, optional, zeroed by the caller).
+    constexpr bool PACKED = std::is_same<PT, P2Cells>::value;
     // cursor of the walking wave (row, column, done) for the second wave of a two-wave launch, which reads the cells the walk is
     // heading for -- the band around the diagonal above the cursor -- ahead of it, so that the window loads hit the L2 instead
     // of paying an HBM miss per window (a freshly filled 1 GB matrix is nowhere near any cache).  Results do not depend on it.
@@ -142,7 +177,16 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
     const int lane = threadIdx.x & 63;
     const int64_t k = blockIdx.x;
     if (res[k].path_len < 0) return;            // the fill of this problem was aborted
-    PT* Pk = P + k * pstride;
+    PT* Pk = PACKED ? P : P + k * pstride;
+    const int64_t koff = PACKED ? k * pstride : 0;                  // (packed: cell offset of problem k inside the byte array)
+    const unsigned char* const pbase = (const unsigned char*)P;
+    auto mark = [&](int64_t idx, int neg_code) {
+        if constexpr (PACKED) {
+            if (pathbits) atomicOr(pathbits + ((koff + idx) >> 5), 1u << (u32)((koff + idx) & 31));
+        } else {
+            Pk[idx] = (PT)neg_code;
+        }
+    };
     const int64_t pos_l = start_pos >= 0 ? start_pos : res[k].max_pos;
     const int64_t pos = ((int64_t)__builtin_amdgcn_readfirstlane((int)(pos_l >> 32)) << 32) | (int64_t)(u32)__builtin_amdgcn_readfirstlane((int)(u32)pos_l);
     const int64_t total = rows1 * M;
@@ -151,7 +195,7 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
         if (threadIdx.x == 0) { cur[0] = pos / M; cur[1] = pos - (pos / M) * M; cur[2] = 0; }
         __syncthreads();
         if (threadIdx.x >= 64) {
-            constexpr int LINE = 128 / (int)sizeof(PT);            // matrix columns per 128-byte line
+            constexpr int LINE = PACKED ? 512 : 128 / (int)sizeof(PT);            // matrix columns per 128-byte line
             int64_t next_row = cur[0];                               // rows above this one are still to be touched
             u32 sink = 0;
             for (;;) {
@@ -169,7 +213,8 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
                             int64_t c = pc + (int64_t)q * LINE;
                             c = c < 0 ? 0 : c;
                             const int64_t idx = r * M + c;
-                            if (idx < total) sink += (u32)__hip_atomic_load((const unsigned char*)(Pk + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L2-served, fills the L2
+                            if (idx < total)   // L2-served, fills the L2
+                                sink += (u32)__hip_atomic_load(PACKED ? pbase + ((koff + idx) >> 2) : (const unsigned char*)(Pk + idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
                     next_row -= 64;
@@ -197,8 +242,16 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
         const uint64_t remain = (uint64_t)(total - w0) * sizeof(PT);
         if (warm && lane == 0) { cur[0] = gi; cur[1] = gj; }
         TB_T(tA);
-        tb_load_window<PT>(Pk + w0, (u32)__builtin_amdgcn_readfirstlane((int)(remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)remain)),
-                           (u32)__builtin_amdgcn_readfirstlane((int)(u32)(M * (int64_t)sizeof(PT))), lane);
+        if constexpr (PACKED)
+        {   // (a window spans at most 64 M + 64 < 2^27 cells: 32-bit byte offsets; the matrix ends nbytes after the corner's byte)
+            const int64_t c0k = koff + w0;
+            const uint64_t nb = (uint64_t)((c0k & 3) + (total - w0) + 3) >> 2;
+            tb_load_window_p2(pbase + (c0k >> 2), (u32)__builtin_amdgcn_readfirstlane((int)(c0k & 3)), (u32)__builtin_amdgcn_readfirstlane((int)(u32)M),
+                              (u32)__builtin_amdgcn_readfirstlane((int)(nb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)nb)), lane);
+        }
+        else
+            tb_load_window<PT>(Pk + w0, (u32)__builtin_amdgcn_readfirstlane((int)(remain > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)remain)),
+                               (u32)__builtin_amdgcn_readfirstlane((int)(u32)(M * (int64_t)sizeof(PT))), lane);
         int status = 0;
 #ifdef TB_PROFILE
         TB_T(tB); t_load += tB - tA; ++nwin;
@@ -227,7 +280,7 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
             for (int i = 0; i < maxc; ++i) {
                 if ((u32)i < ncell) {
                     const int64_t idx = rbase + ecol - i;
-                    Pk[idx] = (PT)((u32)i < cnt ? -SW_LEFT : -(int)code);
+                    mark(idx, (u32)i < cnt ? -SW_LEFT : -(int)code);
                     if (path && poff + i < cap) path[poff + i] = idx;
                 }
             }
@@ -252,7 +305,7 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
                 const u32 before = tb_wave_prefix_sum(d) - d;       // moves made by the earlier steps
                 const int64_t idx = (r0 + si - (int64_t)(before >> 16)) * M + c0 + sj - (int64_t)(before & 0xffffu);
                 if (lane < n) {
-                    Pk[idx] = (PT)(-(int)c);
+                    mark(idx, -(int)c);
                     if (path && len + lane < cap) path[len + lane] = idx;
                 }
                 len += n;
@@ -273,7 +326,8 @@ __global__ void __launch_bounds__(128) sw_traceback_wave(PT* __restrict__ P, int
 #endif
     }
 }
-template __global__ void sw_traceback_wave<int32_t>(int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*, int64_t*);
-template __global__ void sw_traceback_wave<signed char>(signed char*, int64_t, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*, int64_t*);
+template __global__ void sw_traceback_wave<int32_t>(int32_t*, int64_t, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*, int64_t*, unsigned int*);
+template __global__ void sw_traceback_wave<signed char>(signed char*, int64_t, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*, int64_t*, unsigned int*);
+template __global__ void sw_traceback_wave<P2Cells>(P2Cells*, int64_t, int64_t, int64_t, int64_t, int64_t*, int64_t, sw_result*, int64_t*, unsigned int*);
 
 }  // namespace swk

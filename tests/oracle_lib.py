@@ -45,6 +45,10 @@ class Oracle:
         L.swo_row_checksums.argtypes = [vp, i64, i64, vp]
         L.swo_fill_streaming.restype = i64
         L.swo_fill_streaming.argtypes = [vp, i64, vp, i64, ctypes.POINTER(_Scores), vp, vp, ctypes.POINTER(ctypes.c_int32), vp]
+        L.swo_fill_streaming_ckpt.restype = i64
+        L.swo_fill_streaming_ckpt.argtypes = [vp, i64, vp, i64, ctypes.POINTER(_Scores), vp, vp, ctypes.POINTER(ctypes.c_int32), i64, vp, i64, vp, vp]
+        L.swo_path_from_ckpt.restype = i64
+        L.swo_path_from_ckpt.argtypes = [vp, i64, vp, i64, ctypes.POINTER(_Scores), i64, vp, i64, vp, i64, vp]
         self.L = L
 
     def generate(self, cols, rows, seed=1):
@@ -115,6 +119,31 @@ class Oracle:
         mp = self.L.swo_fill_streaming(a.ctypes.data, cols, b.ctypes.data, rows, ctypes.byref(sc), csH.ctypes.data,
                                        csP.ctypes.data, ctypes.byref(ms), bottom.ctypes.data)
         return dict(csH=csH, csP=csP, max_pos=int(mp), max_score=int(ms.value), bottom=bottom)
+
+
+    def fill_streaming_with_path(self, a, b, scores=(3, -3, -2), every=256, band_rows=32768):
+        """Whole-matrix digests without the matrix: row checksums of H, of P before and after the traceback, the
+        path itself, and the H rows at multiples of `every` (band halo rows)."""
+        a, b = _seq(a), _seq(b)
+        cols, rows = len(a), len(b)
+        csH = np.zeros(rows + 1, np.uint64)
+        csP = np.zeros(rows + 1, np.uint64)
+        ckpt = np.zeros((rows // every + 1, cols + 1), np.int32)
+        ms = ctypes.c_int32()
+        sc = _Scores(*scores)
+        nb = -(-rows // band_rows)
+        band_best, band_pos = np.zeros(nb, np.int32), np.zeros(nb, np.int64)
+        mp = self.L.swo_fill_streaming_ckpt(a.ctypes.data, cols, b.ctypes.data, rows, ctypes.byref(sc), csH.ctypes.data,
+                                            csP.ctypes.data, ctypes.byref(ms), every, ckpt.ctypes.data, band_rows, band_best.ctypes.data,
+                                            band_pos.ctypes.data)
+        path = np.zeros(rows + cols + 2, np.int64)
+        delta = np.zeros(rows + 1, np.uint64)
+        n = self.L.swo_path_from_ckpt(a.ctypes.data, cols, b.ctypes.data, rows, ctypes.byref(sc), every, ckpt.ctypes.data,
+                                      mp, path.ctypes.data, len(path), delta.ctypes.data)
+        with np.errstate(over="ignore"):
+            csP1 = csP + delta
+        return dict(csH=csH, csP=csP, csP1=csP1, max_pos=int(mp), max_score=int(ms.value), path=path[:n].copy(),
+                    ckpt=ckpt, every=every, band_best=band_best, band_pos=band_pos)
 
 
 def golden(name):

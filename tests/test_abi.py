@@ -113,3 +113,13 @@ def test_align_auto_host_side_matches_reference(swamd, name):
     assert not r["used_gpu"]
     assert np.array_equal(r["H"], g["H"]) and np.array_equal(r["P"], g["P1"])
     assert r["max_pos"] == int(g["meta"][3]) and r["max_score"] == int(g["meta"][4]) and r["path_len"] == len(g["path"])
+
+
+def test_align_auto_multi_without_devices_is_the_host_leg(swamd):
+    """sw_align_auto_multi with no device and no context: executor 0 (sw_fill_cpu + host traceback), the reference's outputs."""
+    g = golden("rand_300x200_s1")
+    r = swamd.align_auto(g["a"], g["b"], devices=[])
+    assert r["executor"] == 0 and not r["used_gpu"]
+    assert np.array_equal(r["H"], g["H"]) and np.array_equal(r["P"], g["P1"])
+    assert r["max_pos"] == int(g["meta"][3]) and r["path_len"] == len(g["path"])
+    assert swamd.lib().sw_align_auto_multi(None, None, 2, None, 4, None, 4, None, None, None, None, None, 0) == -22

@@ -71,13 +71,17 @@ def test_compact_p_int8(engine, oracle, swamd, engine_kind, cols, rows, h64):
     assert np.array_equal(odd.cpu().numpy(), P1.reshape(-1)[3:-2])
 
 
-def test_config3_65536_int64_streaming_checksums(engine, oracle, swamd, engine_kind):
-    """BASELINE config 3 (65536 x 65536, int64 H + int32 P, resident in HBM): per-row checksums, arg-max, bottom row
-    against the streaming oracle; every int64 H must be the sign extension of its int32 value.  ~20 s."""
-    import torch
+def test_config3_65536_int64_vs_oracle_digest(engine, oracle, swamd, engine_kind):
+    """BASELINE config 3 (65536 x 65536, int64 H + int32 P, resident in HBM) against the streaming oracle's whole-matrix digest
+    (tests/golden/big_digests.json): per-row checksums of H and P, arg-max, the bottom row, the traced-back path (every index) and P
+    after the traceback; every int64 H must be the sign extension of its int32 value (sw_row_checksums_device checks that)."""
+    import json, os, torch
+    from oracle_lib import GOLDEN
     free, _ = torch.cuda.mem_get_info()
     if free < (60 << 30):
         pytest.skip(f"needs 60 GB of free HBM, {free >> 30} GB free")
+    D = json.load(open(os.path.join(GOLDEN, "big_digests.json")))["rand_65536x65536_s1"]
+    fnv = lambda x: f"{oracle.fnv(np.ascontiguousarray(x)):016x}"
     n = 65536
     a, b = swamd.generate(n, n, 1)
     d_a, _ = engine.to_device(a)
@@ -88,12 +92,14 @@ def test_config3_65536_int64_streaming_checksums(engine, oracle, swamd, engine_k
     r = out.result()
     csH, csP = engine.row_checksums(out.H), engine.row_checksums(out.P)
     bottom = out.H[-1].cpu().numpy()
-    st = oracle.fill_streaming(a, b)
-    assert r["max_pos"] == st["max_pos"] and r["max_score"] == st["max_score"]
-    assert np.array_equal(csH, st["csH"]) and np.array_equal(csP, st["csP"])
-    assert np.array_equal(bottom.astype(np.int32), st["bottom"]) and bottom.dtype == np.int64
-    plen = engine.traceback(out, want_path=False)
-    assert n < plen < 3 * n
+    assert r["max_pos"] == D["maxPos"] and r["max_score"] == D["maxScore"]
+    assert fnv(csH) == D["fnv_csH"] and fnv(csP) == D["fnv_csP"]
+    for d in D["bands"]:
+        assert fnv(csH[d["lo"] + 1:d["hi"] + 1]) == d["fnv_csH"] and fnv(csP[d["lo"] + 1:d["hi"] + 1]) == d["fnv_csP"]
+    assert bottom.dtype == np.int64 and fnv(bottom.astype(np.int32)) == D["bands"][-1]["fnv_bottom_H"]
+    path = engine.traceback(out)
+    assert len(path) == D["pathLen"] and fnv(path) == D["fnv_path"] and int(path[-1]) == D["path_end"]
+    assert fnv(engine.row_checksums(out.P)) == D["fnv_csP1"]
 
 
 def test_strip_scan_engine_rejects_compact_p(engine, oracle, swamd):
