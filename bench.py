@@ -213,13 +213,18 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
     fill_gbs = 5 * first.H.numel() * first.H.element_size() / (f0.elapsed_time(f1) * 1e-3) / 1e9
     dt_first, ms_first = timed(first, max(3, args.steps // 2), args.warmup)
     value_first = world * len(ms_first) * cols * rows / dt_first / 1e9
+    t_alloc = 0.0
     if args.placement_trials == 1:
         out, placement_ms = first, None
     else:
         del first
         torch.cuda.empty_cache()
-        # (2) the C-ABI allocator: candidate placements tried with real fills, outside the timed region
+        # (2) the C-ABI allocator: candidate placements classified by its two-stream store probe (or, --placement-trials N, tried with
+        # real fills), outside the timed region
+        eng.set_option("placement_budget_ms", 20000)   # (setup, outside the timed region: the pair is filled into many times)
+        t_alloc = time.perf_counter()
         out, placement_ms = eng.alloc_outputs(d_a, d_b, cols, rows, h_dtype, p_dtype, trials=args.placement_trials)
+        t_alloc = time.perf_counter() - t_alloc
     dt, kern_ms = timed(out, args.steps, args.warmup)
     res = out.result()
     tau_ns, lag_ns, shader_ghz, chain_extra = chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows) if args.engine == 0 else (0.0, 0.0, None, {})
@@ -244,8 +249,13 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
                                f"{'int64' if args.h64 else 'int32'} H + {'int8' if args.p8 else 'int32'} P written to HBM, arg-max tracked",
                    "per_gpu": "one pair per GPU" + (" (replicas)" if world > 1 else ""), "max_pos": res["max_pos"], "max_score": res["max_score"],
                    "grid": eng.get_option("last_grid"), "strips": int(eng.get_option("last_strips2")) or eng.get_option("last_strips"),
-                   "output_buffers": "sw_alloc_outputs (C-ABI allocator, placement chosen by trial fills)" if placement_ms is not None else "plain first allocation",
-                   "placement_trials_ms": placement_ms, "value_first_allocation": value_first, "preheat_fills": nheat,
+                   "output_buffers": ("sw_alloc_outputs (C-ABI allocator: H and P in different classes of the HBM, " +
+                                      ("candidates classified by a two-stream store probe, no trial fills)" if args.placement_trials <= 0 else "placement chosen by trial fills)"))
+                                     if placement_ms is not None else "plain first allocation",
+                   "placement_probe_ms" if args.placement_trials <= 0 else "placement_trials_ms": placement_ms, "sw_alloc_outputs_ms": t_alloc * 1e3,
+                   "placement_ratio": eng.get_option("last_placement_ratio_x1000") / 1000.0 if placement_ms is not None else None,
+                   "value_first_allocation": value_first, "value_first_allocation_is": "the same fill into a plain pair of torch allocations (two back-to-back hipMallocs: usually one class)",
+                   "preheat_fills": nheat,
                    "clocks_before": clocks0, "clocks_after": clocks1, "shader_clock_ghz_in_kernel": shader_ghz,
                    "ms_first_allocation": sum(ms_first) / len(ms_first)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -352,14 +362,15 @@ def run_batch(args, sw, eng, torch, dist, rank, world, local):
         return
     cells = npairs * cols * rows
     bpc = ((0 if args.no_h else 4) + (1 if args.p8 else 4)) if args.store else 0
-    wave = eng.get_option("last_batch_kernel") == 1
+    bk = eng.get_option("last_batch_kernel")
+    wave, packed = bk >= 1, bk == 2
     what = f"{npairs} independent {cols}x{rows} pairs (pair k seeded 1+k) in one call, sequences resident in HBM: "
     what += (f"{'int32 H + ' if not args.no_h else ''}{'int8' if args.p8 else 'int32'} P stored ({bpc} B/cell)" if args.store else "score + exact maxPos only (no matrices)")
     what += ", per-pair traceback" if args.traceback else ""
     line = {"metric": "GCUPS (DP cell updates/s)", "value": args.steps * cells / dt / 1e9, "unit": "GCUPS", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": what, "mode": "batch", "kernel": "sw_batch_wave (one pair per wave)" if wave else "sw_systolic (single-pair machinery)",
+            "config": {"workload": what, "mode": "batch", "kernel": ("sw_batch_wave16 (two pairs per wave, packed 16-bit lanes)" if packed else "sw_batch_wave (one pair per wave)") if wave else "sw_systolic (single-pair machinery)",
                        "device_ms_per_step": e0.elapsed_time(e1) / args.steps}}
     if wave:
         pb = (1 if args.p8 else 4) if args.store else 0
@@ -409,8 +420,9 @@ def main():
     ap.add_argument("--ns", type=int, default=0, help="systolic: strips per workgroup")
     ap.add_argument("--nc", type=int, default=0, help="systolic: consumer waves per strip")
     ap.add_argument("--p8", action="store_true", help="compact predecessor matrix: int8 P")
-    ap.add_argument("--placement-trials", type=int, default=16,
-                    help="pair mode: candidate H/P placements sw_alloc_outputs may try before the timed region (1 = plain allocation)")
+    ap.add_argument("--placement-trials", type=int, default=0,
+                    help="pair mode: 0 = sw_alloc_outputs classifies candidate placements with its store probe (default, no trial fills), "
+                         "1 = plain allocation, > 1 = round 3's search with that many trial fills")
     ap.add_argument("--store-policy", type=int, default=0, help="systolic H/P stores: 0 auto, 1 write-back, 2 streaming")
     ap.add_argument("--importers", type=int, default=0)
     ap.add_argument("--xcd-order", type=int, default=0, help="systolic: 1 = neighbouring strip groups on one XCD")

@@ -1,7 +1,9 @@
 // sw_api.hip -- C-ABI entry points that drive the HIP kernels (see include/swhip.h).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -52,6 +54,9 @@ struct sw_ctx {
     unsigned int* d_part = nullptr;     // sw_prep_scan: one 256-bit presence map of byte values per block (up to 2048 blocks)
     unsigned int* d_sync = nullptr;     // one-launch fills (sw_systolic2's prologue / epilogue): barrier and exit counters, presence map; zero between launches
     unsigned char* d_priv = nullptr; size_t priv_cap = 0;   // ... and every workgroup's own padded copy of b + letter codes
+    int64_t opt_place_budget_ms = 200;  // sw_alloc_outputs: time the search for a P in another class of the HBM may take
+    int place_spacer_gib = 0;           // ... the spacer that led to one last time
+    float last_place_ratio = 0.f;       // ... two-stream / one-stream time of the pair handed out last (~1.3-1.45: different classes, ~2: one class)
     bool key_dirty = false;             // d_key was left non-zero by a launch that does not re-arm it (everything but the one-launch fill)
     bool last_fused = false;            // the last launch_fill reports by itself (no sw_finalize behind it)
     int64_t opt_debug = 0;
@@ -155,6 +160,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "debug_buf")) { c->opt_dbg_ptr = v; return SW_OK; }
     if (!strcmp(name, "batch_lds")) { c->opt_batch_lds = v < 0 ? 0 : v; return SW_OK; }
     if (!strcmp(name, "band_wait_ms")) { c->opt_band_wait_ms = v > 0 ? v : 20000; return SW_OK; }
+    if (!strcmp(name, "placement_budget_ms")) { c->opt_place_budget_ms = v > 0 ? v : 200; return SW_OK; }
     if (!strcmp(name, "debug_epoch8")) { c->epoch8 = (unsigned)(v & 255); return SW_OK; }   // development aid: next launch tag = v + 1
     if (!strcmp(name, "engine")) {
         if (v != 0 && v != 1) { set_err("engine must be 0 (systolic) or 1 (strip_scan)"); return SW_EINVAL; }
@@ -187,6 +193,8 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "last_xcd_mode")) return c->last_xcd_mode;
     if (!strcmp(name, "xcd_round_robin")) return c->xcd_round_robin ? 1 : 0;
     if (!strcmp(name, "last_batch_kernel")) return c->last_batch_kernel;
+    if (!strcmp(name, "placement_budget_ms")) return c->opt_place_budget_ms;
+    if (!strcmp(name, "last_placement_ratio_x1000")) return (int64_t)(c->last_place_ratio * 1000.f);
     return -1;
 }
 
@@ -669,13 +677,17 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
     // an earlier call's scores (a cell outside the matrix may never exceed the cells of the matrix, see the arg-max in sw_batch.hip)
     if (bnd_per) HIP_TRY(hipMemsetAsync(c->d_bnd, 0, (size_t)(chunk * bnd_per) * 4, stream));
     const int64_t cells = (cols + 1) * (rows + 1);
+    unsigned int nletters = 0;
+    // Score-only batches whose scores fit 15 bits run two pairs per wave on packed 16-bit lanes (sw_batch_wave16: 5 VALU per two cells
+    // instead of 8).  (debug bit 18: off, A/B runs)
+    const bool packed16 = !d_H && !d_P && npairs >= 2 && C == 16 && (int64_t)sc->match * std::min(cols, rows) < 32000 && -sc->gap < 32000 && rows < 65000 &&
+                          !(c->opt_debug & 262144);
     for (int64_t k0 = 0; k0 < npairs; k0 += chunk) {
         const int64_t n = std::min(chunk, npairs - k0);
         hipLaunchKernelGGL(swk::sw_batch_codes, dim3((unsigned)std::min<int64_t>((per + 255) / 256, 64), (unsigned)std::min<int64_t>(n, 65535)), dim3(256), 0, stream,
                            ub + k0 * b_stride, rows, b_stride, c->d_bcodes, per, front, (const unsigned int*)c->d_part, 1, c->d_alpha + 64, n);
         HIP_TRY(hipGetLastError());
         if (k0 == 0) {   // the letter count (4 bytes) decides the path: the one host round trip of a batch call
-            unsigned int nletters = 0;
             HIP_TRY(hipMemcpyAsync(&nletters, c->d_alpha + 64 + 256, 4, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             if (nletters > 8u) return 1;
@@ -693,13 +705,21 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
         bp.results = d_results + k0;
         bp.debug = (int)(c->opt_debug & 7);   // bit 0: no matrix stores, bit 1: nt stores, bit 2: sc1 stores (experiments)
         const int pb = d_P ? p_elem_bytes : 0;
+        if (packed16 && n >= 2) {
+            const dim3 grid16((unsigned)(((n + 1) / 2 + 3) / 4)), block16(256);   // 4 waves = 8 pairs per workgroup
+            if (nletters <= 4u) hipLaunchKernelGGL(swk::sw_batch_wave16<true>, grid16, block16, 0, stream, bp);
+            else hipLaunchKernelGGL(swk::sw_batch_wave16<false>, grid16, block16, 0, stream, bp);
+            HIP_TRY(hipGetLastError());
+            c->last_batch_kernel = 2;
+            continue;
+        }
         const dim3 grid((unsigned)((n + 3) / 4)), block(256);   // 4 pairs (waves) per workgroup
 #define SB_LAUNCH(CC, PP) if (C == CC && pb == PP) hipLaunchKernelGGL((swk::sw_batch_wave<CC, PP>), grid, block, (size_t)c->opt_batch_lds, stream, bp);
         SB_LAUNCH(4, 0) SB_LAUNCH(4, 1) SB_LAUNCH(4, 4) SB_LAUNCH(8, 0) SB_LAUNCH(8, 1) SB_LAUNCH(8, 4) SB_LAUNCH(16, 0) SB_LAUNCH(16, 1) SB_LAUNCH(16, 4)
 #undef SB_LAUNCH
         HIP_TRY(hipGetLastError());
     }
-    c->last_batch_kernel = 1;
+    if (c->last_batch_kernel != 2) c->last_batch_kernel = 1;
     c->last_grid = (chunk + 3) / 4; c->last_strips = nstrips;
     return SW_OK;
 }
@@ -801,14 +821,15 @@ int sw_fill_host(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t 
     if (!c || !result || cols < 0 || rows < 0 || (cols > 0 && !a) || (rows > 0 && !b)) { set_err("sw_fill_host: bad argument"); return SW_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
     const size_t cells = (size_t)(cols + 1) * (size_t)(rows + 1);
-    char *d_a = nullptr, *d_b = nullptr; int32_t *d_H = nullptr, *d_P = nullptr; sw_result* d_r = nullptr;
+    char *d_a = nullptr, *d_b = nullptr; void *d_H = nullptr, *d_P = nullptr; sw_result* d_r = nullptr;
     int rc = SW_OK;
-    auto cleanup = [&]() { (void)hipFree(d_a); (void)hipFree(d_b); (void)hipFree(d_H); (void)hipFree(d_P); (void)hipFree(d_r); };
+    auto cleanup = [&]() { (void)hipFree(d_a); (void)hipFree(d_b); if (d_H || d_P) (void)sw_free_outputs(c, d_H, d_P); (void)hipFree(d_r); };
     if (hipMalloc((void**)&d_a, (size_t)cols + 16) != hipSuccess || hipMalloc((void**)&d_b, (size_t)rows + 16) != hipSuccess ||
-        hipMalloc((void**)&d_H, cells * 4) != hipSuccess || hipMalloc((void**)&d_P, cells * 4) != hipSuccess ||
         hipMalloc((void**)&d_r, sizeof(sw_result)) != hipSuccess) {
         cleanup(); set_err("sw_fill_host: device allocation failed"); return SW_ENOMEM;
     }
+    // (H and P from the placement-aware allocator: different classes of the HBM, classified by its store probe -- no trial fills)
+    if ((rc = sw_alloc_outputs(c, nullptr, cols, nullptr, rows, scores, 4, 4, 0, &d_H, &d_P, nullptr)) != SW_OK) { cleanup(); return rc; }
     auto copy = [&](void* dst, const void* src, size_t n, hipMemcpyKind kind, const char* what) {
         if (rc != SW_OK || n == 0) return;
         const hipError_t e = hipMemcpy(dst, src, n, kind);
@@ -816,15 +837,31 @@ int sw_fill_host(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t 
     };
     copy(d_a, a, (size_t)cols, hipMemcpyHostToDevice, "a");
     copy(d_b, b, (size_t)rows, hipMemcpyHostToDevice, "b");
-    if (rc == SW_OK) rc = sw_fill_device(c, d_a, cols, d_b, rows, scores, d_H, 4, d_P, nullptr, d_r, nullptr);
+    if (rc == SW_OK) rc = sw_fill_device(c, d_a, cols, d_b, rows, scores, d_H, 4, (int32_t*)d_P, nullptr, d_r, nullptr);
     if (rc == SW_OK) {
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) { set_err("fill kernel failed: %s", hipGetErrorString(e)); rc = SW_EDEVICE; }
     }
     copy(result, d_r, sizeof(sw_result), hipMemcpyDeviceToHost, "the result");
     if (rc == SW_OK && result->path_len < 0) { set_err("fill kernel: hand-off wait timed out"); rc = SW_ETIMEOUT; }
-    if (H) copy(H, d_H, cells * 4, hipMemcpyDeviceToHost, "H");
-    if (P) copy(P, d_P, cells * 4, hipMemcpyDeviceToHost, "P");
+    // The copy-out is what a host-buffer caller pays: 2 x 4 B per cell over PCIe (16384^2: 2.1 GB, ~40 ms at 55 GB/s against a 0.8 ms
+    // fill).  A pageable destination goes through the runtime's staging buffers at a fraction of that: pin the caller's matrices for the
+    // duration of the copies where the platform allows it, and run the two copies on two streams.
+    if (rc == SW_OK && (H || P)) {
+        const bool pinH = H && cells * 4 >= (64u << 20) && hipHostRegister(H, cells * 4, hipHostRegisterDefault) == hipSuccess;
+        const bool pinP = P && cells * 4 >= (64u << 20) && hipHostRegister(P, cells * 4, hipHostRegisterDefault) == hipSuccess;
+        (void)hipGetLastError();
+        hipStream_t s2 = nullptr;
+        if (pinH && pinP && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { s2 = nullptr; (void)hipGetLastError(); }
+        hipError_t e = hipSuccess;
+        if (H) e = pinH ? hipMemcpyAsync(H, d_H, cells * 4, hipMemcpyDeviceToHost, nullptr) : hipMemcpy(H, d_H, cells * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && P) e = pinP ? hipMemcpyAsync(P, d_P, cells * 4, hipMemcpyDeviceToHost, s2) : hipMemcpy(P, d_P, cells * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (s2) (void)hipStreamDestroy(s2);
+        if (pinH) (void)hipHostUnregister(H);
+        if (pinP) (void)hipHostUnregister(P);
+        if (e != hipSuccess) { set_err("sw_fill_host: copying the matrices back failed: %s", hipGetErrorString(e)); rc = SW_EDEVICE; }
+    }
     cleanup();
     return rc;
 }
@@ -886,11 +923,83 @@ int sw_traceback_device(sw_ctx* c, int32_t* d_P, int64_t cols, int64_t rows, int
     return sw_traceback_device_ex(c, d_P, 4, cols, rows, max_pos, d_path, path_cap, d_result, stream_);
 }
 
-// Output matrices placed for speed.  Where the driver puts H and P in physical memory moves the time of a 16384^2 fill by
-// up to 25 % (two store streams that meet in the same DRAM banks): allocate up to `trials`
-// candidate pairs -- P two MiB out of phase with H, and from the second candidate on a (temporary) spacer block between
-// them so that they come from different 64 GiB segments of the HBM --, time three fills of the caller's problem into each
-// and keep the fastest.
+// Output matrices placed for speed.  Physical HBM falls into a few coarse classes (regions of tens of GiB), and two store streams into
+// the SAME class run ~1.4x slower than into different ones; a fill stores H[r][c] and P[r][c] together, so a 16384^2 fill takes 0.79 ms
+// with H and P in different classes and 1.05 ms with both in one (profiles/r04_placement_classes_probe.log).  Two
+// back-to-back hipMallocs land in one class.  trials <= 0 (the default): candidates for P -- from the second one on behind a temporary
+// spacer allocation, so that they come from elsewhere in the HBM -- are CLASSIFIED against H with the two-stream store probe of
+// csrc/sw_place.hip (~0.3 ms per candidate, no fill of the caller's problem), the first one in another class is kept.  trials == 1: a plain
+// pair.  trials > 1: round 3's search with trial fills of the caller's problem (kept for A/B runs).
+int sw_place_pair_ratio(void* d_X, size_t xbytes, void* d_Y, size_t ybytes, float* ratio, float* ms_together);   // sw_place.hip
+
+static int alloc_outputs_probed(sw_ctx* c, size_t hbytes, size_t pbytes, void** d_H, void** d_P, float* trial_ms, int ntrial_ms) {
+    const size_t phase = 4u << 20;
+    void* H = nullptr;
+    if (hipMalloc(&H, hbytes ? hbytes : 1) != hipSuccess) { (void)hipGetLastError(); set_err("sw_alloc_outputs: %zu bytes do not fit", hbytes); return SW_ENOMEM; }
+    struct Cand { void* base; void* P; float ratio; };
+    std::vector<Cand> cands;
+    // Candidates for P: three plain ones (a class boundary may be right here), then behind temporary spacer allocations (taken only while
+    // 8 GiB of head room remain, released as soon as the candidate behind them exists: the next spacer, of another size, then lands
+    // elsewhere).  The classes are regions of 16 .. 120 GiB in the order the driver hands memory out.  What a spacer costs depends on the
+    // box: memory that was in use before (by this or an earlier process) is wiped by the driver at ~30 GiB/s when it changes hands, fresh
+    // memory costs 0.3 ms per allocation -- so the search runs against a time budget (option "placement_budget_ms", default 200 ms; a
+    // caller that fills many times into the pair raises it) and settles for the best candidate seen when that is spent.  The spacer that
+    // worked is remembered per context and tried first next time.
+    static const int kSpacerGiB[14] = {0, 0, 0, 32, 64, 16, 96, 48, 128, 24, 80, 8, 160, 112};
+    const bool debug = getenv("SW_PLACE_DEBUG") != nullptr;
+    // (a matrix of many GiB spans several classes itself: more sample windows, and the best of a few candidates rather than the first good one)
+    const bool big = std::max(hbytes, pbytes) > (6ull << 30);
+    const float accept = big ? 1.40f : 1.5f;   // another class: ~1.3-1.45; the same class: ~2.0
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    int best = -1, rc = SW_OK;
+    for (int i = 0; i < 14; ++i) {
+        int gib = kSpacerGiB[i];
+        if (i == 3 && c->place_spacer_gib > 0) gib = c->place_spacer_gib;                 // what worked last time, first
+        else if (i > 3 && gib == c->place_spacer_gib) continue;
+        size_t sp = (size_t)gib << 30;
+        if (sp && elapsed_ms() > (double)c->opt_place_budget_ms) break;
+        if (sp) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < sp + pbytes + (8ull << 30)) continue;   // not enough head room for this one
+        }
+        void* spacer = nullptr;
+        if (sp && hipMalloc(&spacer, sp) != hipSuccess) { (void)hipGetLastError(); spacer = nullptr; continue; }
+        Cand k = {nullptr, nullptr, 0.f};
+        const hipError_t e = hipMalloc(&k.base, pbytes + phase);
+        if (spacer) (void)hipFree(spacer);   // (it only steered where P landed)
+        if (e != hipSuccess) { (void)hipGetLastError(); break; }
+        // P two MiB out of phase with H modulo 4 MiB (round 1: neighbouring 2 MiB pages of the two streams)
+        const uintptr_t want = ((uintptr_t)H + (2u << 20)) % phase;
+        k.P = (char*)k.base + (want + phase - ((uintptr_t)k.base % phase)) % phase;
+        float ms = 0.f;
+        rc = sw_place_pair_ratio(H, hbytes, k.P, pbytes, &k.ratio, &ms);
+        cands.push_back(k);
+        if (rc != SW_OK) break;
+        if (debug) fprintf(stderr, "sw_alloc_outputs: candidate %d (spacer %d GiB): H %p P %p ratio %.3f (%.3f ms), %.1f ms so far\n", i, gib, H, k.P, k.ratio, ms, elapsed_ms());
+        if (trial_ms && (int)cands.size() <= ntrial_ms) trial_ms[cands.size() - 1] = ms;
+        const int prev_best = best;
+        if (best < 0 || k.ratio < cands[best].ratio) best = (int)cands.size() - 1;
+        if (big) {   // candidates of tens of GiB: only the best so far stays allocated
+            const int loser = best == (int)cands.size() - 1 ? prev_best : (int)cands.size() - 1;
+            if (loser >= 0 && cands[loser].base) { (void)hipFree(cands[loser].base); cands[loser].base = nullptr; }
+        }
+        if (k.ratio < accept) { if (gib) c->place_spacer_gib = gib; break; }
+        if (big && cands.size() >= 5) break;   // (... and the best of five)
+    }
+    for (int i = 0; i < (int)cands.size(); ++i)
+        if ((i != best || rc != SW_OK) && cands[i].base) (void)hipFree(cands[i].base);
+    if (rc != SW_OK || best < 0) {
+        (void)hipFree(H);
+        if (rc == SW_OK) { set_err("sw_alloc_outputs: %zu + %zu bytes do not fit", hbytes, pbytes); rc = SW_ENOMEM; }
+        return rc;
+    }
+    c->last_place_ratio = cands[best].ratio;
+    *d_H = H; *d_P = cands[best].P;
+    c->out_base[cands[best].P] = cands[best].base;
+    return SW_OK;
+}
+
 int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores, int h_elem_bytes,
                      int p_elem_bytes, int trials, void** d_H, void** d_P, float* trial_ms) {
     if (!c || !d_H || !d_P || cols < 0 || rows < 0 || (h_elem_bytes != 4 && h_elem_bytes != 8) || (p_elem_bytes != 4 && p_elem_bytes != 1) ||
@@ -901,8 +1010,14 @@ int sw_alloc_outputs(sw_ctx* c, const char* d_a, int64_t cols, const char* d_b, 
     HIP_TRY(hipSetDevice(c->device));
     const size_t cells = (size_t)(cols + 1) * (size_t)(rows + 1);
     const size_t hbytes = cells * (size_t)h_elem_bytes, pbytes = cells * (size_t)p_elem_bytes;
-    // (below half a GiB of output the strip chain bounds a fill, not the stores: no search -- its spacer allocations alone take seconds)
-    if (trials <= 0) trials = (hbytes + pbytes < (512ull << 20)) ? 1 : 16;
+    // (below half a GiB of output the strip chain bounds a fill, not the stores: a plain pair)
+    if (trials <= 0) {
+        if (hbytes + pbytes >= (512ull << 20)) {
+            for (int i = 0; i < 16 && trial_ms; ++i) trial_ms[i] = 0.f;
+            return alloc_outputs_probed(c, hbytes, pbytes, d_H, d_P, trial_ms, 16);
+        }
+        trials = 1;
+    }
     const size_t phase = 4u << 20;
     struct Cand { void* H; void* Pbase; void* P; void* spacer; float ms; };
     std::vector<Cand> cands;

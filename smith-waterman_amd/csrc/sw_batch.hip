@@ -330,6 +330,225 @@ __global__ void __launch_bounds__(256) sw_batch_wave(BatchParams p) {
     }
 }
 
+// ---- TWO pairs per wave on packed 16-bit lanes (round 4) --------------------------------------------------------------------------------
+// Where every score of a pair fits 15 bits (match * min(cols, rows) < 2^15: 1024^2 reads score at most 3072) the recurrence runs on
+// VOP3P instructions: the low half of every register belongs to pair 2w, the high half to pair 2w + 1 of the batch (same shape, same
+// step numbering: lane l works on row u - l of BOTH pairs).  Per pair of cells
+//     u2 = v_pk_max_u16(H_up, H_left)          t.lo / t.hi = v_add_u32_sdwa(H_diag.word, sext(S.byte))   (one per half: VOP3P has no SDWA)
+//     ug = v_pk_sub_u16(u2, -gap) clamp        H = v_pk_max_i16(t, ug)
+// -- the unsigned saturating subtract makes ug >= 0, so the maximum with the (possibly negative) t IS the floor at 0: 5 VALU for two cells
+// where the 32-bit kernel needs 8.  No P, no H: score + exact maxPos only (the other output modes stay on sw_batch_wave).
+// Arg-max, exact: the row maximum of a lane's 16 cells is a binary tree of v_pk_max_u16 (15); in the steps that reach the best score a
+// pair has shown so far (a wave-uniform threshold, one saturating subtract + compare per step) a descent through the tree in packed
+// arithmetic (b = min(m - left child, 1) is 0 where the left child holds the maximum; children are picked with v_pk_mad_u16) yields the
+// FIRST column that holds it (30), and the lane's record (best, step, column) is updated with a strict "better than before" (7) -- for
+// both pairs at once.  A lane's record is exact for the lane; the lanes are merged at the end by
+// the reference's rule (highest score, lowest linear index).  Cells outside the matrix need no masking: they derive from cells of the
+// matrix by strictly negative moves, so they stay below the pair's maximum and can only spoil the record of a lane that does not hold it.
+#define SB_PK2(OP, D, A, B) asm(OP " %0, %1, %2" : "=v"(D) : "v"(A), "v"(B))
+__device__ __forceinline__ u32 pk_max_u16(u32 a, u32 b) { u32 d; SB_PK2("v_pk_max_u16", d, a, b); return d; }
+__device__ __forceinline__ u32 pk_min_u16(u32 a, u32 b) { u32 d; SB_PK2("v_pk_min_u16", d, a, b); return d; }
+__device__ __forceinline__ u32 pk_max_i16(u32 a, u32 b) { u32 d; SB_PK2("v_pk_max_i16", d, a, b); return d; }
+__device__ __forceinline__ u32 pk_sub_u16(u32 a, u32 b) { u32 d; SB_PK2("v_pk_sub_u16", d, a, b); return d; }             // wraps
+__device__ __forceinline__ u32 pk_subs_u16(u32 a, u32 b) { u32 d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }   // saturates at 0
+__device__ __forceinline__ u32 pk_mad_u16(u32 a, u32 b, u32 c) { u32 d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// t = {dprev.lo + sext(SA.byte J), dprev.hi + sext(SB.byte J)}
+template <int J>
+__device__ __forceinline__ u32 pk_add_sbytes(u32 dprev, u32 SA, u32 SB) {
+    u32 t;
+    if constexpr (J == 0) {
+        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_0" : "=v"(t) : "v"(dprev), "v"(SA));
+        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_0" : "+v"(t) : "v"(dprev), "v"(SB));
+    } else if constexpr (J == 1) {
+        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_1" : "=v"(t) : "v"(dprev), "v"(SA));
+        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1" : "+v"(t) : "v"(dprev), "v"(SB));
+    } else if constexpr (J == 2) {
+        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_2" : "=v"(t) : "v"(dprev), "v"(SA));
+        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_2" : "+v"(t) : "v"(dprev), "v"(SB));
+    } else {
+        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_3" : "=v"(t) : "v"(dprev), "v"(SA));
+        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3" : "+v"(t) : "v"(dprev), "v"(SB));
+    }
+    return t;
+}
+
+// one cell of both pairs as ONE statement (the compiler pads every dependent pair of asm statements with an s_nop it cannot prove
+// unnecessary: 3 per cell when the five instructions are five statements)
+#define SB_PK_CELL(BYTE)                                                                                                              \
+    asm("v_add_u32_sdwa %0, %3, sext(%4) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:" BYTE "\n\t"                    \
+        "v_pk_max_u16 %1, %6, %7\n\t"                                                                                                 \
+        "v_add_u32_sdwa %0, %3, sext(%5) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:" BYTE "\n\t"               \
+        "v_pk_sub_u16 %1, %1, %8 clamp\n\t"                                                                                           \
+        "v_pk_max_i16 %2, %0, %1"                                                                                                     \
+        : "=&v"(t), "=&v"(u2), "=v"(hn) : "v"(dprev), "v"(SA), "v"(SB), "v"(old), "v"(prev), "v"(gg))
+template <int J>
+__device__ __forceinline__ u32 pk_cell(u32 dprev, u32 SA, u32 SB, u32 old, u32 prev, u32 gg) {
+    u32 t, u2, hn;
+    if constexpr (J == 0) SB_PK_CELL("BYTE_0");
+    else if constexpr (J == 1) SB_PK_CELL("BYTE_1");
+    else if constexpr (J == 2) SB_PK_CELL("BYTE_2");
+    else SB_PK_CELL("BYTE_3");
+    return hn;
+}
+
+// C = 16 columns per lane; LE4: the batch has at most 4 distinct letters (codes 0..3: the upper half of the score profiles is never selected)
+template <bool LE4>
+__global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams p) {   // (LE4: 4 waves per SIMD, at most 128 VGPRs)
+    constexpr int C = 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t couple = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    const int64_t pairA = 2 * couple;
+    if (pairA >= p.npairs) return;
+    const int64_t pairB = pairA + 1 < p.npairs ? pairA + 1 : pairA;   // (an odd batch: the last wave runs its pair in both halves)
+    const int cols = (int)p.cols, rows = (int)p.rows, M = cols + 1;
+    const unsigned char* __restrict__ aA = p.a + pairA * p.a_pstride;
+    const unsigned char* __restrict__ aB = p.a + pairB * p.a_pstride;
+    const unsigned char* __restrict__ bclA = p.bcode + pairA * p.bcode_pstride + p.bfront - 1 - lane;   // bcl[u] = code of b[u - lane - 1]
+    const unsigned char* __restrict__ bclB = p.bcode + pairB * p.bcode_pstride + p.bfront - 1 - lane;
+    const int nstrips = (cols + 64 * C - 1) / (64 * C);
+    const bool multi = nstrips > 1;
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)(multi ? p.bnd + pairA * p.bnd_pstride : nullptr), 0,
+                                                                        multi ? (int)(p.bnd_pstride * 4) : 0, 0x00020000);   // (the couple shares pair A's boundary row: packed values)
+    const u32 mis4 = 0x01010101u * (u32)(unsigned char)(signed char)p.mismatch;
+    const u32 dmm = ((u32)(unsigned char)(signed char)p.match) ^ ((u32)(unsigned char)(signed char)p.mismatch);
+    const u32 gg = (u32)p.ngap * 0x00010001u, one2 = 0x00010001u;
+    u64 kbestA = 0, kbestB = 0;
+    const int G = (rows + 64 + 3) / 4;
+
+    for (int st = 0; st < nstrips; ++st) {
+        const int c0 = st * 64 * C + lane * C + 1;
+        u32 loA[C], loB[C], hiA[LE4 ? 1 : C], hiB[LE4 ? 1 : C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const int c = c0 + k;
+            u32 la = 0xFFFFFFFFu, ha = 0xFFFFFFFFu, lb = 0xFFFFFFFFu, hb = 0xFFFFFFFFu;   // outside the matrix: -1 against everything
+            if (c <= cols) {
+                const u32 ca = p.atab[aA[c - 1]], cb = p.atab[aB[c - 1]];
+                la = mis4 ^ (ca < 4u ? dmm << (8 * ca) : 0u);
+                ha = mis4 ^ (ca >= 4u && ca < 8u ? dmm << (8 * (ca - 4u)) : 0u);
+                lb = mis4 ^ (cb < 4u ? dmm << (8 * cb) : 0u);
+                hb = mis4 ^ (cb >= 4u && cb < 8u ? dmm << (8 * (cb - 4u)) : 0u);
+            }
+            loA[k] = la; loB[k] = lb;
+            if constexpr (!LE4) { hiA[k] = ha; hiB[k] = hb; }
+        }
+        u32 h[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) h[k] = 0u;
+        u32 diag0 = 0u, lbest = 0u, lk = 0u, lstep = 0u;
+        u32 sb1 = 0u;          // wave-uniform: {best score seen so far - 1} of both pairs (at least 1 - 1: zeros never count)
+        const bool bw = multi && st + 1 < nstrips, br = multi && st > 0;
+        sb_v4i bq = {0, 0, 0, 0};
+        const u32 voffB = lane == 0 ? 64u * 4u : SB_OOB;
+        if (br) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bq = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)voffB, 0, 16);
+        }
+        u32 selA_next, selB_next;
+        __builtin_memcpy(&selA_next, bclA, 4);
+        __builtin_memcpy(&selB_next, bclB, 4);
+
+        for (int g = 0; g < G; ++g) {
+            const u32 selA = selA_next, selB = selB_next;
+            __builtin_memcpy(&selA_next, bclA + 4 * (g + 1), 4);     // codes of the next 4 rows (the padded copy covers the overrun)
+            __builtin_memcpy(&selB_next, bclB + 4 * (g + 1), 4);
+            u32 SA[C], SB[C];
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                SA[k] = __builtin_amdgcn_perm(LE4 ? loA[k] : hiA[k], loA[k], selA);
+                SB[k] = __builtin_amdgcn_perm(LE4 ? loB[k] : hiB[k], loB[k], selB);
+            }
+            const sb_v4i bcur = bq;
+            if (br) bq = __builtin_amdgcn_raw_buffer_load_b128(rB, (int)voffB, 16 * (g + 1), 16);
+
+            sb_for<0, 4>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const int u = 4 * g + j;
+                const u32 left = (u32)sb_dpp_shr1(br ? bcur[j] : 0, (int)h[C - 1]);
+                u32 dprev = diag0, prev = left;
+                diag0 = left;
+                sb_for<0, C>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    const u32 old = h[k];
+                    const u32 hn = pk_cell<j>(dprev, SA[k], SB[k], old, prev, gg);
+                    h[k] = hn;
+                    dprev = old;
+                    prev = hn;
+                });
+                if (bw) __builtin_amdgcn_raw_buffer_store_b32((int)h[C - 1], rB, lane == 63 ? 4 : (int)SB_OOB, 4 * u, 0);   // row u - 63 at index row + 64
+                // ---- arg-max: tree of row maxima, first column that holds the maximum, strict update of the lane's record
+                u32 n1[8], n2[4], n3[2];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) n1[i] = pk_max_u16(h[2 * i], h[2 * i + 1]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) n2[i] = pk_max_u16(n1[2 * i], n1[2 * i + 1]);
+                n3[0] = pk_max_u16(n2[0], n2[1]); n3[1] = pk_max_u16(n2[2], n2[3]);
+                const u32 m = pk_max_u16(n3[0], n3[1]);
+                // Only a step in which some lane reaches the best score its pair has shown so far (either half) can hold that pair's arg-max:
+                // the others skip the search.  sb1 = {bestA - 1, bestB - 1} is wave-uniform and may lag behind (it is raised from ONE of
+                // the lanes that passed): a lower threshold only lets more steps through.
+                if (__builtin_amdgcn_ballot_w64(pk_subs_u16(m, sb1) != 0u) != 0) {
+                    // b = 0 where the LEFT child holds the maximum (the lower columns win a tie), else 1; sel(b, x, y) = b ? y : x
+                    auto isnot = [&](u32 node) { return pk_min_u16(pk_sub_u16(m, node), one2); };
+                    auto sel = [&](u32 b, u32 x, u32 y) { return pk_mad_u16(b, pk_sub_u16(y, x), x); };
+                    const u32 b3 = isnot(n3[0]);
+                    const u32 b2 = isnot(sel(b3, n2[0], n2[2]));
+                    const u32 b1 = isnot(sel(b3, sel(b2, n1[0], n1[2]), sel(b2, n1[4], n1[6])));
+                    const u32 b0 = isnot(sel(b3, sel(b2, sel(b1, h[0], h[2]), sel(b1, h[4], h[6])), sel(b2, sel(b1, h[8], h[10]), sel(b1, h[12], h[14]))));
+                    const u32 two2 = 0x00020002u;
+                    const u32 kk = pk_mad_u16(pk_mad_u16(pk_mad_u16(b3, two2, b2), two2, b1), two2, b0);   // 8 b3 + 4 b2 + 2 b1 + b0
+                    const u32 imp = pk_min_u16(pk_subs_u16(m, lbest), one2);                              // 1 where m > the lane's best so far
+                    const u32 upk = (u32)__builtin_amdgcn_readfirstlane(u * 0x00010001);
+                    lbest = pk_max_u16(lbest, m);
+                    lk = sel(imp, lk, kk);
+                    lstep = sel(imp, lstep, upk);
+                    const u64 pass = __builtin_amdgcn_ballot_w64(pk_subs_u16(m, sb1) != 0u);
+                    const u32 mL = (u32)__builtin_amdgcn_readlane((int)m, (int)__builtin_ctzll(pass));
+                    const u32 sbA = max((sb1 & 0xffffu) + 1u, mL & 0xffffu), sbB = max((sb1 >> 16) + 1u, mL >> 16);
+                    sb1 = (u32)__builtin_amdgcn_readfirstlane((int)(((sbB - 1u) << 16) | (sbA - 1u)));
+                }
+            });
+        }
+        {
+            auto rec = [&](u32 best, u32 step, u32 k, u64& kb) {
+                const int r = (int)step - lane, c = c0 + (int)k;
+                if (best > 0u && r >= 1 && r <= rows && c <= cols) {
+                    const u64 key = ((u64)best << 40) | (SW_KEY_IDX_MASK - (u64)(u32)(r * M + c));
+                    kb = key > kb ? key : kb;
+                }
+            };
+            rec(lbest & 0xffffu, lstep & 0xffffu, lk & 0xffffu, kbestA);
+            rec(lbest >> 16, lstep >> 16, lk >> 16, kbestB);
+        }
+    }
+    // each pair's arg-max: highest score, lowest linear index among equals (serial_smithW.c:240-242)
+    auto reduce = [&](u64 kb) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const u32 olo = (u32)__shfl_xor((int)(u32)kb, off), ohi = (u32)__shfl_xor((int)(u32)(kb >> 32), off);
+            const u64 o = ((u64)ohi << 32) | olo;
+            kb = o > kb ? o : kb;
+        }
+        return kb;
+    };
+    kbestA = reduce(kbestA); kbestB = reduce(kbestB);
+    if (lane == 0) {
+        sw_result* res = p.results + pairA;
+        res->max_score = (int64_t)(kbestA >> 40);
+        res->max_pos = kbestA ? (int64_t)(SW_KEY_IDX_MASK - (kbestA & SW_KEY_IDX_MASK)) : 0;
+        res->path_len = 0;
+        if (pairB != pairA) {
+            res = p.results + pairB;
+            res->max_score = (int64_t)(kbestB >> 40);
+            res->max_pos = kbestB ? (int64_t)(SW_KEY_IDX_MASK - (kbestB & SW_KEY_IDX_MASK)) : 0;
+            res->path_len = 0;
+        }
+    }
+}
+template __global__ void sw_batch_wave16<true>(BatchParams);
+template __global__ void sw_batch_wave16<false>(BatchParams);
+
 #define SB_INST(C, PB) template __global__ void sw_batch_wave<C, PB>(BatchParams);
 SB_INST(4, 0) SB_INST(4, 1) SB_INST(4, 4) SB_INST(8, 0) SB_INST(8, 1) SB_INST(8, 4) SB_INST(16, 0) SB_INST(16, 1) SB_INST(16, 4)
 #undef SB_INST

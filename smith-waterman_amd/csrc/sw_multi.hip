@@ -133,12 +133,11 @@ int sw_multi_create(const int* devices, int ndev, const char* a, int64_t cols, c
         bool ok = dev_alloc((void**)&bd.d_a, (size_t)cols + 16) && dev_alloc((void**)&bd.d_b, (size_t)br + 16) &&
                   hipMemcpy(bd.d_a, a, (size_t)cols, hipMemcpyHostToDevice) == hipSuccess &&
                   hipMemcpy(bd.d_b, b + bd.lo, (size_t)br, hipMemcpyHostToDevice) == hipSuccess;
-        // A band with a GPU of its own takes H and P from the placement-aware allocator (trial fills of the band's own problem:
-        // where the two matrices lie in HBM moves a fill by 15-30 %).  Bands sharing a GPU cannot: a trial
-        // fill wants the whole device.
+        // A band with a GPU of its own takes H and P from the placement-aware allocator (H and P in different classes of the HBM: where
+        // the two matrices lie moves a fill by 15-30 %; candidates are classified by a store probe, no trial fills).
+        // Bands sharing a GPU take plain pairs: the probe wants the device to itself.
         if (ok && want_h && share0 == 1) {
-            const sw_scores trial = {3, -3, -2};
-            ok = sw_alloc_outputs(bd.ctx, bd.d_a, cols, bd.d_b, br, &trial, 4, p_elem_bytes, cells > (1ull << 32) ? 4 : 0, &bd.d_H, &bd.d_P, nullptr) == SW_OK;
+            ok = sw_alloc_outputs(bd.ctx, bd.d_a, cols, bd.d_b, br, nullptr, 4, p_elem_bytes, 0, &bd.d_H, &bd.d_P, nullptr) == SW_OK;
             bd.placed = ok;
         } else {
             ok = ok && (!want_h || dev_alloc(&bd.d_H, cells * 4)) && dev_alloc(&bd.d_P, cells * (size_t)p_elem_bytes);

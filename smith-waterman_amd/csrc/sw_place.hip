@@ -7,6 +7,7 @@
 // microseconds instead of with trial fills of the caller's problem.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "sw_kernels.h"
 
 namespace swh { void set_err(const char* fmt, ...); }
@@ -64,6 +65,35 @@ int sw_probe_streams(sw_ctx* c, void* d_X, void* d_Y, int64_t rows, int64_t pitc
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (e != hipSuccess) { set_err("sw_probe_streams: %s", hipGetErrorString(e)); return SW_EDEVICE; }
     *ms = t / reps;
+    return SW_OK;
+}
+
+// How much slower are two store streams into (X, Y) together than one stream into X alone?  ~1.3 when X and Y lie in different
+// classes of the HBM, ~1.9 when they share one (profiles/r04_placement_classes_probe.log: 0.146 against 0.215 ms for 2 x 256 MiB, one
+// stream alone 0.11 ms).  Samples `nwin` windows of `win` bytes at the same relative positions of the two buffers (a big matrix spans
+// several classes; rows of H and P that are written together sit at the same relative position) and returns the mean ratio.  The probe
+// WRITES the windows: both buffers must be fresh.  Default stream; ~0.2 ms per window.
+int sw_place_pair_ratio(void* d_X, size_t xbytes, void* d_Y, size_t ybytes, float* ratio, float* ms_together) {
+    if (!d_X || !d_Y || !ratio) { set_err("sw_place_pair_ratio: bad argument"); return SW_EINVAL; }
+    const size_t win = std::min<size_t>(std::min(xbytes, ybytes), 128ull << 20);
+    const int64_t pitch = 65540, rows = (int64_t)(win / (size_t)pitch);
+    if (rows < 64) { *ratio = 1.f; if (ms_together) *ms_together = 0.f; return SW_OK; }
+    const int nwin = std::max(xbytes, ybytes) > (6ull << 30) ? 8 : 1;
+    float sum = 0.f, tsum = 0.f;
+    for (int w = 0; w < nwin; ++w) {
+        // window w starts at the fraction (w + 1/2) / nwin of each buffer (256-byte aligned), whole inside it
+        auto at = [&](size_t bytes) { const size_t room = bytes - win; return ((size_t)((double)room * ((double)w + 0.5) / (double)nwin)) & ~(size_t)255; };
+        unsigned char* X = (unsigned char*)d_X + (nwin == 1 ? 0 : at(xbytes));
+        unsigned char* Y = (unsigned char*)d_Y + (nwin == 1 ? 0 : at(ybytes));
+        float one = 0.f, two = 0.f;
+        int rc = sw_probe_streams(nullptr, X, nullptr, rows, pitch, 63, 4, 1, 3, &one);
+        if (rc == SW_OK) rc = sw_probe_streams(nullptr, X, Y, rows, pitch, 63, 4, 0, 3, &two);
+        if (rc != SW_OK) return rc;
+        sum += one > 0.f ? two / one : 1.f;
+        tsum += two;
+    }
+    *ratio = sum / (float)nwin;
+    if (ms_together) *ms_together = tsum / (float)nwin;
     return SW_OK;
 }
 

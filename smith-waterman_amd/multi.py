@@ -208,8 +208,8 @@ class BandResident(BandPipeline):
             self.placement_ms = []
             if placement and (world == 1 or self.nccl) and want_h:
                 # where H and P lie in HBM moves the fill by 15-30 %: take them from the C-ABI allocator,
-                # which tries a few placements with fills of this band.  Its trial fills use the whole GPU, so not when
-                # several ranks may share one (gloo rehearsals).
+                # which puts them into different classes of the HBM (candidates classified by a store probe).  The probe wants the GPU
+                # to itself, so not when several ranks may share one (gloo rehearsals).
                 self._out, self.placement_ms = engine.alloc_outputs(self.d_a, self.d_b, self.cols, br, p_dtype=p_dtype, scores=scores,
                                                                     trials=self._placement_trials(br, p_dtype))
                 self.H, self.P = self._out.H, self._out.P
@@ -240,7 +240,7 @@ class BandResident(BandPipeline):
         # every candidate holds one more copy of P until the search ends: fewer candidates for bands that fill the HBM
         cells = (br + 1) * (self.cols + 1)
         total = cells * (4 + (1 if p_dtype is not None and p_dtype.itemsize == 1 else 4))
-        return 0 if cells <= (1 << 32) else (4 if total <= (100 << 30) else 2)
+        return 0   # (round 4: the allocator classifies candidates with its store probe -- no trial fills, losers of a big search freed at once)
 
     # Cut at even granule indices: every forwarded piece is then 16-byte aligned, so no transport has a reason to move a
     # granule in pieces smaller than its 8 bytes (a granule is valid only as a whole).  A granule that is cut off rides

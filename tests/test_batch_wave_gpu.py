@@ -120,3 +120,61 @@ def test_traceback_long_paths(engine, oracle, shape):
         assert len(path) == len(opath) and np.array_equal(path, opath)
         assert np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
         assert out.result()["path_len"] == len(opath)
+
+
+# ---- two pairs per wave on packed 16-bit lanes (sw_batch_wave16: score-only batches of 513+ columns whose scores fit 15 bits) ----------
+def _check16(engine, oracle, A, B, scores=(3, -3, -2), expect=2):
+    res, _, _ = engine.batch(A, B, scores=scores, store=False)
+    assert engine.get_option("last_batch_kernel") == expect
+    res = res.cpu().numpy()
+    for k in range(A.shape[0]):
+        h, p, mp = oracle.fill(A[k], B[k], scores)
+        assert res[k, 0] == mp and res[k, 1] == int(h.flat[mp]) and res[k, 2] == 0, f"pair {k}: {res[k]} vs maxPos {mp} score {int(h.flat[mp])}"
+
+
+@pytest.mark.parametrize("cols,rows,npairs", [(513, 1, 2), (600, 70, 9), (1024, 300, 8), (1000, 129, 3), (777, 64, 17), (1023, 65, 2), (1024, 1024, 5)])
+def test_packed16_shapes_even_and_odd_batches(engine, oracle, cols, rows, npairs):
+    A, B = _pairs(np.random.default_rng(cols + 7 * rows), npairs, cols, rows)
+    _check16(engine, oracle, A, B)
+
+
+@pytest.mark.parametrize("cols,rows", [(1025, 50), (1500, 300), (2500, 200)])
+def test_packed16_wider_than_one_strip(engine, oracle, cols, rows):
+    A, B = _pairs(np.random.default_rng(cols), 5, cols, rows)
+    _check16(engine, oracle, A, B)
+
+
+@pytest.mark.parametrize("letters", [1, 2, 3, 4, 5, 7, 8])
+def test_packed16_alphabets(engine, oracle, letters):
+    """up to 4 letters: the half-size score profiles (LE4); 5..8: both halves"""
+    A, B = _pairs(np.random.default_rng(letters), 6, 700, 150, letters)
+    _check16(engine, oracle, A, B)
+
+
+@pytest.mark.parametrize("scores", [(5, -3, -4), (1, -1, -1), (2, 1, -1), (3, -3, 0), (10, -20, -7), (0, 0, 0), (100, -100, -90)])
+def test_packed16_scorings(engine, oracle, scores):
+    A, B = _pairs(np.random.default_rng(abs(hash(scores)) % 1000), 6, 640, 120)
+    _check16(engine, oracle, A, B, scores=scores)
+
+
+def test_packed16_ties_identical_and_disjoint_pairs(engine, oracle):
+    """periodic sequences (the maximum is attained in many cells of a row and of a lane: the lowest linear index wins), all-match (the
+    highest scores the shape allows), no match at all, and two very different pairs sharing a wave"""
+    cols, rows = 800, 300
+    A = np.tile(np.frombuffer(b"ACGT", np.uint8), (8, cols // 4))
+    B = np.tile(np.frombuffer(b"ACGT", np.uint8), (8, rows // 4))
+    A[1], B[1] = 65, 65
+    A[2], B[2] = 65, 67
+    A[3] = np.frombuffer(b"AC", np.uint8).repeat(cols // 2)
+    B[4] = np.frombuffer(b"GT", np.uint8).repeat(rows // 2)
+    A[6], B[6] = 71, 71
+    A[7], B[7] = 84, 67
+    _check16(engine, oracle, A, B)
+
+
+def test_packed16_falls_back_when_scores_need_more_than_15_bits(engine, oracle):
+    A, B = _pairs(np.random.default_rng(5), 4, 1024, 900)
+    A[1], B[1] = 65, 65                                  # all-match: 900 x 40 = 36000 > 2^15
+    _check16(engine, oracle, A, B, scores=(40, -3, -2), expect=1)
+    A, B = _pairs(np.random.default_rng(6), 1, 1024, 100)   # a single pair has nobody to share a wave with
+    _check16(engine, oracle, A, B, expect=1)

@@ -1,0 +1,52 @@
+"""GPU: sw_alloc_outputs -- the placement-aware allocator (probe-based since round 4) hands out usable, distinct buffers quickly, results do
+not depend on it, and dropping a pair returns its memory."""
+import gc
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_probe_based_allocation_is_fast_and_correct(engine, oracle, swamd):
+    import torch
+    n = 12288                                   # 1.2 GB of output: above the 512 MiB below which a plain pair is handed out
+    if torch.cuda.mem_get_info()[0] < (40 << 30):
+        pytest.skip("needs 40 GB of free HBM")
+    a, b = swamd.generate(n, n, 3)
+    d_a, _ = engine.to_device(a)
+    d_b, _ = engine.to_device(b)
+    engine.synchronize()
+    t0 = time.perf_counter()
+    out, ms = engine.alloc_outputs(d_a, d_b, n, n)
+    dt = time.perf_counter() - t0
+    assert 1 <= len(ms) <= 12 and dt < 0.5, (ms, dt)      # (0.3 ms per candidate on an idle box; the bound is generous)
+    assert out.H.data_ptr() != out.P.data_ptr()
+    engine.fill_into(out, d_a, d_b)
+    engine.synchronize()
+    st = oracle.fill_streaming(a, b)
+    r = out.result()
+    assert (r["max_pos"], r["max_score"]) == (st["max_pos"], st["max_score"])
+    assert np.array_equal(engine.row_checksums(out.H), st["csH"]) and np.array_equal(engine.row_checksums(out.P), st["csP"])
+
+
+def test_dropping_a_pair_returns_its_memory(engine, swamd):
+    import torch
+    n = 12288
+    if torch.cuda.mem_get_info()[0] < (40 << 30):
+        pytest.skip("needs 40 GB of free HBM")
+    a, b = swamd.generate(n, n, 3)
+    d_a, _ = engine.to_device(a)
+    d_b, _ = engine.to_device(b)
+    engine.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    out, _ = engine.alloc_outputs(d_a, d_b, n, n)
+    held = free0 - torch.cuda.mem_get_info()[0]
+    assert held >= 2 * (n + 1) * (n + 1) * 4
+    del out
+    gc.collect()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20), "a dropped Fill must release its sw_alloc_outputs pair"
+    out, _ = engine.alloc_outputs(d_a, d_b, n, n)
+    out.free()                                  # explicit release
+    assert out.H is None and torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
