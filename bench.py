@@ -152,16 +152,36 @@ def chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows):
     return tau, lag, ghz, extra
 
 
+def _pmc_file():
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        f = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(f):
+            return f
+    return None
+
+
 def traffic_for(workload_key, kernel=None):
-    """HBM bytes per launch from the committed PMC passes (scripts/gpu_pmc.sh), if they were taken on the kernel that ran."""
+    """HBM bytes per launch from the COMMITTED PMC passes (scripts/gpu_ci.sh, rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE in separate
+    runs) -- not measured in this run: returns (bytes, where they come from)."""
     try:
-        f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-        pm = json.load(open(f if os.path.exists(f) else os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"))).get(workload_key, {})
+        f = _pmc_file()
+        pm = json.load(open(f)).get(workload_key, {})
         if kernel and pm.get("kernel") and pm["kernel"] != kernel:
-            return None
-        return pm.get("traffic_bytes_per_launch")
+            return None, None
+        return pm.get("traffic_bytes_per_launch"), f"profiles/{os.path.basename(f)} (rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE of an earlier run of this workload; not measured in this run)"
     except Exception:
-        return None
+        return None, None
+
+
+def batch_valu_per_step(label):
+    """VALU instructions one wave issues per step of the batch kernel (a row of its pair -- or of its two pairs -- x 1024 columns), from the
+    committed PMC pass (SQ_INSTS_VALU per launch / steps, scripts/collect_profiles.py); None when there is no such pass."""
+    try:
+        f = _pmc_file()
+        e = json.load(open(f)).get(label)
+        return (e["VALU_per_step"], f"profiles/{os.path.basename(f)}: SQ_INSTS_VALU / (waves x steps) of '{label}'") if e else (None, None)
+    except Exception:
+        return None, None
 
 
 def run_pair(args, sw, eng, torch, dist, rank, world, local):
@@ -240,6 +260,7 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
     avg_ms = sum(kern_ms) / len(kern_ms)
     achieved = bytes_per_cell * cells / (avg_ms * 1e-3) / 1e9
     key = f"{cols}x{rows} {'int64' if args.h64 else 'int32'} H + {'int8' if args.p8 else 'int32'} P"
+    traffic, traffic_src = traffic_for(key, "sw_systolic2" if int(eng.get_option("last_strips2")) > 0 else "sw_systolic") if args.engine == 0 else (None, None)
     line = {
         "metric": "GCUPS (DP cell updates/s) on NxN random DNA pair", "value": world * args.steps * cells / dt / 1e9,
         "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -248,7 +269,7 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
         "config": {"workload": f"{cols}x{rows} random DNA pair (reference generator, seed 1+rank), linear gap 3/-3/-2, "
                                f"{'int64' if args.h64 else 'int32'} H + {'int8' if args.p8 else 'int32'} P written to HBM, arg-max tracked",
                    "per_gpu": "one pair per GPU" + (" (replicas)" if world > 1 else ""), "max_pos": res["max_pos"], "max_score": res["max_score"],
-                   "grid": eng.get_option("last_grid"), "strips": int(eng.get_option("last_strips2")) or eng.get_option("last_strips"),
+                   "grid": eng.get_option("last_grid"), "column_tiles": eng.get_option("last_tiles"), "strips": int(eng.get_option("last_strips2")) or eng.get_option("last_strips"),
                    "output_buffers": ("sw_alloc_outputs (C-ABI allocator: H and P in different classes of the HBM, " +
                                       ("candidates classified by a two-stream store probe, no trial fills)" if args.placement_trials <= 0 else "placement chosen by trial fills)"))
                                      if placement_ms is not None else "plain first allocation",
@@ -260,7 +281,7 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
                    "ms_first_allocation": sum(ms_first) / len(ms_first)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic_for(key, "sw_systolic2" if int(eng.get_option("last_strips2")) > 0 else "sw_systolic") if args.engine == 0 else None,
+                     "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": ("sw_systolic2" if int(eng.get_option("last_strips2")) > 0 else "sw_systolic") if args.engine == 0 else "sw_strip_scan", "avg_launch_ms": avg_ms, "min_launch_ms": min(kern_ms),
                      "algorithmic_bytes_per_cell": bytes_per_cell, "measured_contiguous_fill_GBs": fill_gbs,
                      "tau_step_ns": tau_ns, "strip_handoff_lag_ns": lag_ns, **chain_extra,
@@ -327,9 +348,6 @@ def run_bands(args, sw, eng, torch, dist, rank, world, local):
 
 
 VALU_PEAK_GWIPS = 1024 * 2.4 / 4.0   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 clk per SIMD at 2.4 GHz (G wave-instr/s)
-# instructions the batch kernel (sw_batch_wave<16, PB>) issues per step = one row x 1024 columns of a pair, counted in its ISA
-# (scripts/count_batch_isa.py): score + exact arg-max only / int8 P stored / int32 P stored; H stored adds 5
-BATCH_INSTR_PER_STEP = {0: 84, 1: 186, 4: 176}
 
 
 def run_batch(args, sw, eng, torch, dist, rank, world, local):
@@ -369,17 +387,20 @@ def run_batch(args, sw, eng, torch, dist, rank, world, local):
     what += ", per-pair traceback" if args.traceback else ""
     line = {"metric": "GCUPS (DP cell updates/s)", "value": args.steps * cells / dt / 1e9, "unit": "GCUPS", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
+            "dtype": "int16" if packed else "int32", "data": "synthetic",
             "config": {"workload": what, "mode": "batch", "kernel": ("sw_batch_wave16 (two pairs per wave, packed 16-bit lanes)" if packed else "sw_batch_wave (one pair per wave)") if wave else "sw_systolic (single-pair machinery)",
                        "device_ms_per_step": e0.elapsed_time(e1) / args.steps}}
     if wave:
         pb = (1 if args.p8 else 4) if args.store else 0
-        ipstep = BATCH_INSTR_PER_STEP[pb] + (5 if (args.store and not args.no_h) else 0)
-        steps = npairs * (rows + 64) * -(-cols // 1024)
-        ach = steps * ipstep / (dt / args.steps) / 1e9
-        line["roofline"] = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GWIPS, "traffic": None,
-                            "kernel": f"sw_batch_wave<16,{pb}>", "instructions_per_1024_cell_step": ipstep,
+        label = "batch kernel, packed 16-bit, score + arg-max only" if packed else ("batch kernel, int8 P stored" if pb == 1 else ("batch kernel, score + arg-max only" if pb == 0 else None))
+        ipstep, isrc = batch_valu_per_step(label) if label else (None, None)
+        wsteps = (npairs // 2 if packed else npairs) * (rows + 64) * -(-cols // 1024)     # steps all waves together take
+        line["roofline"] = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": None, "traffic": None,
+                            "kernel": "sw_batch_wave16<LE4>" if packed else f"sw_batch_wave<16,{pb}>",
                             "note": "integer max/add recurrence: no contraction, so no MFMA; the bound is vector issue (1 wave64 instruction per 4 clk per SIMD)"}
+        if ipstep:
+            ach = wsteps * ipstep / (dt / args.steps) / 1e9
+            line["roofline"].update({"achieved": ach, "frac": ach / VALU_PEAK_GWIPS, "valu_instructions_per_wave_step": ipstep, "valu_instructions_source": isrc})
         if bpc:
             hb = bpc * cells / (dt / args.steps) / 1e9
             line["roofline"]["hbm"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS, "algorithmic_bytes_per_cell": bpc}

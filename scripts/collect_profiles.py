@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Summarises what scripts/gpu_ci.sh left in gpurun_out/ (bench lines, rocprofv3 kernel stats / traces, PMC passes) and, with
---copy, puts the files that are judged under profiles/r03_*.
+--copy, puts the files that are judged under profiles/r04_*.
 
-  python3 scripts/collect_profiles.py gpurun_out            # on the GPU box: summary on stdout + gpurun_out/r03_pmc_traffic.json
+  python3 scripts/collect_profiles.py gpurun_out            # on the GPU box: summary on stdout + gpurun_out/r04_pmc_traffic.json
   python3 scripts/collect_profiles.py gpurun_out --copy     # in the build container: copy into profiles/
 """
 import collections
@@ -91,17 +91,19 @@ for key, wtag, ftag, kern, alg in (("16384x16384 int32 H + int32 P", "cfg2_WRITE
         out[key] = {"WRITE_SIZE_bytes": wb, "FETCH_SIZE_bytes_raw": fb, "traffic_bytes_per_launch": wb + 2 * fb, "algorithmic_bytes_per_launch": alg,
                     "traffic_over_algorithmic": (wb + 2 * fb) / alg, "kernel": kern}
         print(f"{key}: WRITE {wb / 1e9:.2f} GB, FETCH (x2) {2 * fb / 1e9:.2f} GB, traffic / algorithmic = {(wb + 2 * fb) / alg:.3f}")
-for tag, pairs, label in (("batch_score_SQ", 20000, "score + arg-max only"), ("batch_p8_SQ", 20000, "int8 P stored")):
-    c = counters(tag, "sw_batch_wave")
+# (steps: what all waves of the launch take together -- one wave per pair, or per two pairs in the packed kernel -- x 1088 steps each)
+for tag, pairs, label, kern, per_wave in (("batch_score_SQ", 20000, "packed 16-bit, score + arg-max only", "sw_batch_wave16", 2),
+                                          ("batch_score32_SQ", 20000, "score + arg-max only", "sw_batch_wave<", 1), ("batch_p8_SQ", 20000, "int8 P stored", "sw_batch_wave<", 1)):
+    c = counters(tag, kern)
     if c:
-        steps = pairs * 1088
+        steps = pairs // per_wave * 1088
         info = {k: v[-1] for k, v in c.items()}
-        out["batch kernel, " + label] = {**info, "steps_1024_cells": steps, "VALU_per_step": info.get("SQ_INSTS_VALU", 0) / steps,
+        out["batch kernel, " + label] = {**info, "wave_steps": steps, "pairs_per_wave": per_wave, "VALU_per_step": info.get("SQ_INSTS_VALU", 0) / steps,
                                          "SALU_per_step": info.get("SQ_INSTS_SALU", 0) / steps}
-        print(f"batch kernel ({label}): VALU {info.get('SQ_INSTS_VALU', 0) / steps:.1f} + SALU {info.get('SQ_INSTS_SALU', 0) / steps:.1f} instructions per step of 1024 cells")
+        print(f"batch kernel ({label}): VALU {info.get('SQ_INSTS_VALU', 0) / steps:.1f} + SALU {info.get('SQ_INSTS_SALU', 0) / steps:.1f} instructions per wave and step ({per_wave} x 1024 cells)")
 if timed:
     out["timed launches of the default bench (rocprofv3 --kernel-trace)"] = timed
-json.dump(out, open(os.path.join(src, "r03_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(src, "r04_pmc_traffic.json"), "w"), indent=1)
 
 if copy:
     os.makedirs(prof, exist_ok=True)
@@ -110,18 +112,18 @@ if copy:
     for f in sorted(glob.glob(os.path.join(src, "bench*.log"))):
         d = bench_line(f)
         if d and os.path.basename(f)[:-4] in steps:
-            json.dump(d, open(os.path.join(prof, "r03_" + os.path.basename(f)[:-4] + ".json"), "w"))
+            json.dump(d, open(os.path.join(prof, "r04_" + os.path.basename(f)[:-4] + ".json"), "w"))
             n += 1
-    for name, dst in (("ci.log", "r03_ci.log"), ("profile_summary.log", "r03_profile_summary.log"), ("r03_pmc_traffic.json", "r03_pmc_traffic.json"),
-                      ("cli_16384.log", "r03_cli.log"), ("cli_2bands_1gpu_16384.log", "r03_cli_2bands_1gpu.log"), ("pytest_gpu.log", "r03_pytest_gpu.log"),
-                      ("ubench_scope.log", "r03_ubench_scope.log")):
+    for name, dst in (("ci.log", "r04_ci.log"), ("profile_summary.log", "r04_profile_summary.log"), ("r04_pmc_traffic.json", "r04_pmc_traffic.json"),
+                      ("cli_16384.log", "r04_cli.log"), ("cli_2bands_1gpu_16384.log", "r04_cli_2bands_1gpu.log"), ("pytest_gpu.log", "r04_pytest_gpu.log"),
+                      ("ubench_scope.log", "r04_ubench_scope.log"), ("pmc/placement_summary.json", "r04_placement_tcc_counters_same_vs_different_class.json")):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(prof, dst)); n += 1
     for d, tag in (("prof", ""), ("prof_batch", "_batch")):
         for f in newest(os.path.join(src, d, "**", "*kernel_stats.csv")):
-            shutil.copy(f, os.path.join(prof, f"r03_kernel_stats{tag}.csv")); n += 1
+            shutil.copy(f, os.path.join(prof, f"r04_kernel_stats{tag}.csv")); n += 1
         for f in newest(os.path.join(src, d, "**", "*kernel_trace.csv")):
             # the trace is long (one line per launch): keep the last 400 lines
             lines = open(f).read().splitlines()
-            open(os.path.join(prof, f"r03_kernel_trace{tag}.csv"), "w").write("\n".join(lines[:1] + lines[1:][-400:]) + "\n"); n += 1
+            open(os.path.join(prof, f"r04_kernel_trace{tag}.csv"), "w").write("\n".join(lines[:1] + lines[1:][-400:]) + "\n"); n += 1
     print(f"copied {n} files into profiles/")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): parity tests, smoke, the bench lines of every BASELINE config that fits one GPU, rocprofv3
 # kernel traces and PMC passes of the default bench and of the batch kernel.  A step that times out / is killed stops the chain.
-# Everything lands in gpurun_out/; scripts/collect_profiles.py copies what is judged into profiles/r03_*.
+# Everything lands in gpurun_out/; scripts/collect_profiles.py copies what is judged into profiles/r04_*.
 set -u
 mkdir -p gpurun_out
 step() {  # step <name> <timeout_s> <cmd...>
@@ -29,14 +29,20 @@ step bench_no_xcd_roles 200 python bench.py --steps 20 --warmup 3 --no-cpu --deb
 step bench_no_scouts 200 python bench.py --steps 20 --warmup 3 --no-cpu --debug-flags 131072
 step bench_one_column 200 python bench.py --steps 20 --warmup 3 --no-cpu --debug-flags 16384
 step bench_first_alloc 200 python bench.py --steps 20 --warmup 3 --no-cpu --placement-trials 1
+step bench_trial_fill_search 200 python bench.py --steps 20 --warmup 3 --no-cpu --placement-trials 16
 step bench_p8 200 python bench.py --steps 20 --warmup 3 --no-cpu --p8
 # ---- other sizes
 step bench_i32_8k 200 python bench.py --steps 20 --warmup 3 --no-cpu --cols 8192 --rows 8192
 step bench_i32_12k 200 python bench.py --steps 20 --warmup 3 --no-cpu --cols 12288 --rows 12288
 step bench_i32_18k 200 python bench.py --steps 10 --warmup 3 --no-cpu --cols 18432 --rows 18432
 step bench_i32_20k 200 python bench.py --steps 10 --warmup 3 --no-cpu --cols 20480 --rows 20480
+step bench_i32_24k 300 python bench.py --steps 5 --warmup 2 --no-cpu --cols 24576 --rows 24576
 step bench_i32_32k 300 python bench.py --steps 5 --warmup 2 --no-cpu --cols 32768 --rows 32768
+step bench_i32_32k_untiled 300 python bench.py --steps 5 --warmup 2 --no-cpu --cols 32768 --rows 32768 --debug-flags 524288
+step bench_i32_40k 300 python bench.py --steps 5 --warmup 2 --no-cpu --cols 40000 --rows 40000
+step bench_i32_48k 300 python bench.py --steps 3 --warmup 1 --no-cpu --cols 49152 --rows 49152
 step bench_i32_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536
+step bench_i32_64k_untiled 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --debug-flags 524288
 # ---- config 3
 step bench_h64_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64
 # ---- config 4 on one GPU: the per-rank shape of the 8-GPU run, the whole matrix P-only, two ranks rehearsing over gloo
@@ -46,6 +52,7 @@ step bench_gpus2_gloo_self_spawned 500 python bench.py --gpus 2 --backend gloo -
 step bench_gpus4_gloo_one_gpu 500 python bench.py --gpus 4 --backend gloo --steps 2 --warmup 1 --cols 32768 --rows 32768
 # ---- config 5
 step bench_batch_100k_scoreonly 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1
+step bench_batch_100k_scoreonly_32bit 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1 --no-cpu --debug-flags 262144
 step bench_batch_100k_p8 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1 --store --p8 --no-h --no-cpu
 step bench_batch_100k_p8_traceback 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1 --store --p8 --no-h --traceback --no-cpu
 step bench_batch_100k_old_path 400 python bench.py --mode batch --pairs 100000 --steps 1 --warmup 1 --no-cpu --debug-flags 65536
@@ -67,7 +74,10 @@ pmc cfg2_FETCH_SIZE FETCH_SIZE --steps 5 --warmup 1 --placement-trials 1
 pmc cfg3_WRITE_SIZE WRITE_SIZE --steps 2 --warmup 1 --placement-trials 1 --cols 65536 --rows 65536 --h64
 pmc cfg3_FETCH_SIZE FETCH_SIZE --steps 2 --warmup 1 --placement-trials 1 --cols 65536 --rows 65536 --h64
 pmc batch_score_SQ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --mode batch --pairs 20000 --steps 1 --warmup 1
+pmc batch_score32_SQ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --mode batch --pairs 20000 --steps 1 --warmup 1 --debug-flags 262144
 pmc batch_p8_SQ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --mode batch --pairs 20000 --steps 1 --warmup 1 --store --p8 --no-h
 pmc batch_p8_WRITE_SIZE WRITE_SIZE --mode batch --pairs 20000 --steps 1 --warmup 1 --store --p8 --no-h
 pmc batch_p8_FETCH_SIZE FETCH_SIZE --mode batch --pairs 20000 --steps 1 --warmup 1 --store --p8 --no-h
+# ---- placement: TCC write counters of the same fill into a same-class and a different-class pair
+step placement_pmc 400 bash scripts/gpu_placement_pmc.sh
 python3 scripts/collect_profiles.py gpurun_out | tee gpurun_out/profile_summary.log

@@ -81,6 +81,7 @@ struct sw_ctx {
     int64_t last_strips2 = 0;           // strips of the two-column kernel in the last launch (0: not launched)
     int64_t last_scouts = 0;            // scout workgroups of that launch
     int64_t last_xcd_mode = 0;          // that launch dealt its roles per XCD
+    int64_t last_tiles = 1;             // column tiles (launches of the two-column kernel) of the last fill
     bool xcd_round_robin = false;       // sw_xcc_probe saw workgroup i on XCD i % 8 (8 XCDs of 32 CUs)
     std::map<void*, void*> out_base;    // sw_alloc_outputs: pointer handed out -> allocation to free
 };
@@ -191,6 +192,7 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "last_strips2")) return c->last_strips2;
     if (!strcmp(name, "last_scouts")) return c->last_scouts;
     if (!strcmp(name, "last_xcd_mode")) return c->last_xcd_mode;
+    if (!strcmp(name, "last_tiles")) return c->last_tiles;
     if (!strcmp(name, "xcd_round_robin")) return c->xcd_round_robin ? 1 : 0;
     if (!strcmp(name, "last_batch_kernel")) return c->last_batch_kernel;
     if (!strcmp(name, "placement_budget_ms")) return c->opt_place_budget_ms;
@@ -441,12 +443,51 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         }
         const unsigned char* cbp = c->d_cb;
         bool launched = false;
-        c->last_strips2 = 0; c->last_scouts = 0; c->last_xcd_mode = 0;
+        c->last_strips2 = 0; c->last_scouts = 0; c->last_xcd_mode = 0; c->last_tiles = 1;
         if (two_cols) {
-            const int64_t S2 = (cols + 125) / 126;
+            const int64_t S2all = (cols + 125) / 126;
+            // Column tiles.  Scout workgroups beside one filler per strip (sw_systolic2.inc) need 1.5 .. 2 workgroups per strip: up to ~170
+            // strips (21 000 columns) on 256 CUs.  A wider matrix used to run the classic chain, fillers handing over to fillers at 7 us per
+            // strip (32768^2: 349 GCUPS).  Now it is cut into column tiles of at most 160 strips, ONE LAUNCH EACH, every one with scouts,
+            // roles per XCD and paced fillers; a tile's left halo is the previous tile's last column, read from H itself (kernel boundary:
+            // no flags), the arg-max accumulates in the key across the launches and the last one reports.  Taken where the estimate says
+            // it pays: not where the stores bound the fill anyway (int64 H at 65536^2), not for bands (their halo row arrives while they
+            // run).  (debug bit 19: off)
+            int64_t ntile = 1, tstrips = S2all;
+            if (S2all > 170 && base_mode && j.stride == cols + 1 && j.d_result && !(c->opt_debug & 524288)) {
+                const int64_t nt = (S2all + 159) / 160, st = (S2all + nt - 1) / nt;
+                // measured (one box, GCUPS tiled / untiled): 24576^2 314 / 277, 32768^2 376 / 330, 40000^2 328 / 394, 49152^2 308 / 406 -- a tile
+                // ramps up and drains its chain with the stores idle (3.0 TB/s on average where the untiled fill of a big matrix keeps 3.3),
+                // so tiles pay while the untiled fill is bound by its 7 us hand-offs, up to ~36 000 columns
+                const double bytes = (double)(cols + 1) * (double)(rows + 1) * 8.0;
+                const double t_tiles = (double)nt * std::max((double)st * 2.4e-6 + (double)(rows + 200) * 26e-9, bytes / (double)nt / 3.0e12);
+                const double t_classic = std::max((double)S2all * 7.6e-6 + (double)rows * 35e-9, bytes / 3.3e12);
+                if (t_tiles < 0.98 * t_classic) { ntile = nt; tstrips = st; }
+            }
+            c->last_tiles = ntile;
+            for (int64_t tile = 0; tile < ntile; ++tile) {
+            const int64_t c0 = tile * tstrips * 126, tcols = std::min<int64_t>(cols - c0, tstrips * 126);
+            const int64_t S2 = (tcols + 125) / 126;
             swk::FillParams p2 = p;
             p2.nstrips = (int)S2;
             p2.h_bytes = j.h_elem_bytes;
+            p2.cols = tcols;
+            if (ntile > 1) p2.store_nt = c->opt_store_policy == 2 || (c->opt_store_policy == 0 && (double)tcols * (double)rows <= 6.0e8);   // (per launch, as for a matrix of the tile's size)
+            p2.alpha_a = ua; p2.alpha_cols = cols;
+            p2.idx_off = c0; p2.final_launch = tile + 1 == ntile ? 1 : 0;
+            if (ntile > 1) {
+                p2.H = (char*)j.d_H + c0 * 4; p2.P = (int32_t*)((char*)j.d_P + c0 * 4);
+                p2.tile_left = tile ? (const int32_t*)j.d_H + c0 : nullptr;
+                if (tile) {   // the edge values of this context are self-tagged with the launch tag: every tile launch has its own
+                    if (++c->epoch8 >= (unsigned)((c->opt_debug & 1024) ? 4 : 256)) {
+                        const unsigned nb = (unsigned)std::max<size_t>(1, std::min<size_t>((c->edge4_cap + 255) / 256, 2048));
+                        hipLaunchKernelGGL(swk::sw_wipe_u32, dim3(nb), dim3(256), 0, stream, c->d_edge4, c->edge4_cap);
+                        c->epoch8 = 1;
+                    }
+                    p2.gbias = (c->epoch8 << 24) | 0x10000u;
+                }
+            }
+            const unsigned char* ua_t = ua + c0;
             const int per_cu = per_cu2;
             {
                 int grid2 = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(S2, maxb), (int64_t)per_cu * c->num_cus));
@@ -504,16 +545,18 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 // consumer waves (+ 9 - nc2 importers).  Behind scouts a filler is never the one a hand-off waits for: two importers do, and seven
                 // consumers keep more stores in flight (16384^2 -1.5 %, 12288^2 -2.5 %, 20480^2 +-0 against five)
                 const int nc2 = c->opt_consumers == 0 ? (scouts ? 7 : (chain_bound ? 5 : 6)) : (int)std::min<int64_t>(7, c->opt_consumers);
-                if (nc2 == 7) hipLaunchKernelGGL(swk::sw_systolic2<7>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
-                else if (nc2 == 6) hipLaunchKernelGGL(swk::sw_systolic2<6>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
-                else if (nc2 == 5) hipLaunchKernelGGL(swk::sw_systolic2<5>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
-                else hipLaunchKernelGGL(swk::sw_systolic2<4>, dim3(grid2), dim3(768), 0, stream, ua, ub, p2);
-                // the fall-back (an alphabet of more than 7 letters, known on the device only): enqueued behind, leaves at once otherwise
-                p.skip_if_perm = 1;
-                p.sync = c->d_sync; p.atab_w = c->d_alpha + 64; p.result = j.d_result;
+                if (nc2 == 7) hipLaunchKernelGGL(swk::sw_systolic2<7>, dim3(grid2), dim3(768), 0, stream, ua_t, ub, p2);
+                else if (nc2 == 6) hipLaunchKernelGGL(swk::sw_systolic2<6>, dim3(grid2), dim3(768), 0, stream, ua_t, ub, p2);
+                else if (nc2 == 5) hipLaunchKernelGGL(swk::sw_systolic2<5>, dim3(grid2), dim3(768), 0, stream, ua_t, ub, p2);
+                else hipLaunchKernelGGL(swk::sw_systolic2<4>, dim3(grid2), dim3(768), 0, stream, ua_t, ub, p2);
                 c->last_strips2 = S2;
-                c->last_fused = true;
             }
+            }   // (tiles)
+            // the fall-back (an alphabet of more than 7 letters, known on the device only): enqueued behind, leaves at once otherwise;
+            // it fills the whole matrix by itself, whatever the tiling
+            p.skip_if_perm = 1;
+            p.sync = c->d_sync; p.atab_w = c->d_alpha + 64; p.result = j.d_result; p.final_launch = 1;
+            c->last_fused = true;
         }
         if (!two_cols) { prepare(nullptr, nullptr, false); c->key_dirty = true; }
 #define SW_LAUNCH(ns, nc)                                                                                                        \

@@ -338,11 +338,10 @@ __global__ void __launch_bounds__(256) sw_batch_wave(BatchParams p) {
 //     ug = v_pk_sub_u16(u2, -gap) clamp        H = v_pk_max_i16(t, ug)
 // -- the unsigned saturating subtract makes ug >= 0, so the maximum with the (possibly negative) t IS the floor at 0: 5 VALU for two cells
 // where the 32-bit kernel needs 8.  No P, no H: score + exact maxPos only (the other output modes stay on sw_batch_wave).
-// Arg-max, exact: the row maximum of a lane's 16 cells is a binary tree of v_pk_max_u16 (15); in the steps that reach the best score a
-// pair has shown so far (a wave-uniform threshold, one saturating subtract + compare per step) a descent through the tree in packed
-// arithmetic (b = min(m - left child, 1) is 0 where the left child holds the maximum; children are picked with v_pk_mad_u16) yields the
-// FIRST column that holds it (30), and the lane's record (best, step, column) is updated with a strict "better than before" (7) -- for
-// both pairs at once.  A lane's record is exact for the lane; the lanes are merged at the end by
+// Arg-max, exact and without a branch: the row maximum of a lane's 16 cells is a binary tree of v_pk_max_u16 (15), a descent through the
+// tree in packed arithmetic (b = min(m - left child, 1) is 0 where the left child holds the maximum; children are picked with
+// v_pk_mad_u16) yields the FIRST column that holds it (30), and the lane's record (best, step, column) is updated with a strict "better
+// than before" (7) -- all for both pairs at once, every step.  A lane's record is exact for the lane; the lanes are merged at the end by
 // the reference's rule (highest score, lowest linear index).  Cells outside the matrix need no masking: they derive from cells of the
 // matrix by strictly negative moves, so they stay below the pair's maximum and can only spoil the record of a lane that does not hold it.
 #define SB_PK2(OP, D, A, B) asm(OP " %0, %1, %2" : "=v"(D) : "v"(A), "v"(B))
@@ -437,7 +436,6 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
 #pragma unroll
         for (int k = 0; k < C; ++k) h[k] = 0u;
         u32 diag0 = 0u, lbest = 0u, lk = 0u, lstep = 0u;
-        u32 sb1 = 0u;          // wave-uniform: {best score seen so far - 1} of both pairs (at least 1 - 1: zeros never count)
         const bool bw = multi && st + 1 < nstrips, br = multi && st > 0;
         sb_v4i bq = {0, 0, 0, 0};
         const u32 voffB = lane == 0 ? 64u * 4u : SB_OOB;
@@ -485,29 +483,22 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
                 for (int i = 0; i < 4; ++i) n2[i] = pk_max_u16(n1[2 * i], n1[2 * i + 1]);
                 n3[0] = pk_max_u16(n2[0], n2[1]); n3[1] = pk_max_u16(n2[2], n2[3]);
                 const u32 m = pk_max_u16(n3[0], n3[1]);
-                // Only a step in which some lane reaches the best score its pair has shown so far (either half) can hold that pair's arg-max:
-                // the others skip the search.  sb1 = {bestA - 1, bestB - 1} is wave-uniform and may lag behind (it is raised from ONE of
-                // the lanes that passed): a lower threshold only lets more steps through.
-                if (__builtin_amdgcn_ballot_w64(pk_subs_u16(m, sb1) != 0u) != 0) {
-                    // b = 0 where the LEFT child holds the maximum (the lower columns win a tie), else 1; sel(b, x, y) = b ? y : x
-                    auto isnot = [&](u32 node) { return pk_min_u16(pk_sub_u16(m, node), one2); };
-                    auto sel = [&](u32 b, u32 x, u32 y) { return pk_mad_u16(b, pk_sub_u16(y, x), x); };
-                    const u32 b3 = isnot(n3[0]);
-                    const u32 b2 = isnot(sel(b3, n2[0], n2[2]));
-                    const u32 b1 = isnot(sel(b3, sel(b2, n1[0], n1[2]), sel(b2, n1[4], n1[6])));
-                    const u32 b0 = isnot(sel(b3, sel(b2, sel(b1, h[0], h[2]), sel(b1, h[4], h[6])), sel(b2, sel(b1, h[8], h[10]), sel(b1, h[12], h[14]))));
-                    const u32 two2 = 0x00020002u;
-                    const u32 kk = pk_mad_u16(pk_mad_u16(pk_mad_u16(b3, two2, b2), two2, b1), two2, b0);   // 8 b3 + 4 b2 + 2 b1 + b0
-                    const u32 imp = pk_min_u16(pk_subs_u16(m, lbest), one2);                              // 1 where m > the lane's best so far
-                    const u32 upk = (u32)__builtin_amdgcn_readfirstlane(u * 0x00010001);
-                    lbest = pk_max_u16(lbest, m);
-                    lk = sel(imp, lk, kk);
-                    lstep = sel(imp, lstep, upk);
-                    const u64 pass = __builtin_amdgcn_ballot_w64(pk_subs_u16(m, sb1) != 0u);
-                    const u32 mL = (u32)__builtin_amdgcn_readlane((int)m, (int)__builtin_ctzll(pass));
-                    const u32 sbA = max((sb1 & 0xffffu) + 1u, mL & 0xffffu), sbB = max((sb1 >> 16) + 1u, mL >> 16);
-                    sb1 = (u32)__builtin_amdgcn_readfirstlane((int)(((sbB - 1u) << 16) | (sbA - 1u)));
-                }
+                // b = 0 where the LEFT child holds the maximum (the lower columns win a tie), else 1; sel(b, x, y) = b ? y : x
+                // (tried: the search only in steps that reach the pair's best so far, behind a wave-uniform threshold -- 7214 against 7170
+                //  GCUPS: some lane of the 64 is near its pair's best in almost every step, the branch saves next to nothing)
+                auto isnot = [&](u32 node) { return pk_min_u16(pk_sub_u16(m, node), one2); };
+                auto sel = [&](u32 b, u32 x, u32 y) { return pk_mad_u16(b, pk_sub_u16(y, x), x); };
+                const u32 b3 = isnot(n3[0]);
+                const u32 b2 = isnot(sel(b3, n2[0], n2[2]));
+                const u32 b1 = isnot(sel(b3, sel(b2, n1[0], n1[2]), sel(b2, n1[4], n1[6])));
+                const u32 b0 = isnot(sel(b3, sel(b2, sel(b1, h[0], h[2]), sel(b1, h[4], h[6])), sel(b2, sel(b1, h[8], h[10]), sel(b1, h[12], h[14]))));
+                const u32 two2 = 0x00020002u;
+                const u32 kk = pk_mad_u16(pk_mad_u16(pk_mad_u16(b3, two2, b2), two2, b1), two2, b0);   // 8 b3 + 4 b2 + 2 b1 + b0
+                const u32 imp = pk_min_u16(pk_subs_u16(m, lbest), one2);                              // 1 where m > the lane's best so far
+                const u32 upk = (u32)__builtin_amdgcn_readfirstlane(u * 0x00010001);
+                lbest = pk_max_u16(lbest, m);
+                lk = sel(imp, lk, kk);
+                lstep = sel(imp, lstep, upk);
             });
         }
         {

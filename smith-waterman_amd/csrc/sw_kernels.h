@@ -67,6 +67,12 @@ struct FillParams {
     unsigned char* bpad8_w; unsigned char* bcode_w; unsigned char* atab_w;
     sw_result* result;                   // != NULL: the last workgroup to leave writes the result and re-arms key / abort flag / sync for the next launch
     int skip_row0;                       // prologue: row 0 of H / P is not this launch's to clear (a band's halo row)
+    // column tiles of one matrix, one launch each (round 4: matrices too wide for scout workgroups beside one filler per strip)
+    const int32_t* tile_left;            // H of the column left of this tile's first column, row r at tile_left[r * M] (the previous tile wrote it); NULL: zeros
+    int64_t idx_off;                     // added to the linear index of the arg-max (the tile's first column: indices of the whole matrix)
+    int final_launch;                    // the epilogue reports and re-arms the key (earlier tiles only accumulate into it)
+    const unsigned char* alpha_a;        // what the prologue scans for letters: the WHOLE a (every tile must decide alike who fills)
+    int64_t alpha_cols;
 };
 constexpr int SW_XTAB_OFF = 448;         // atab + 448: unsigned int[256], XCD + 1 of every workgroup of the running sw_systolic2 launch (0: not there yet)
 constexpr int SW_PERM_PAD = -100;        // score of any cell outside the sequences (perm producer)
