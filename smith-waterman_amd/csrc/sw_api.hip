@@ -54,6 +54,7 @@ struct sw_ctx {
     unsigned int* d_part = nullptr;     // sw_prep_scan: one 256-bit presence map of byte values per block (up to 2048 blocks)
     unsigned int* d_sync = nullptr;     // one-launch fills (sw_systolic2's prologue / epilogue): barrier and exit counters, presence map; zero between launches
     unsigned char* d_priv = nullptr; size_t priv_cap = 0;   // ... and every workgroup's own padded copy of b + letter codes
+    int64_t opt_split_blk = 0, opt_split_from = 0;   // split strips: forced split block / first strip (0: chosen by the library; tests)
     int64_t opt_place_budget_ms = 200;  // sw_alloc_outputs: time the search for a P in another class of the HBM may take
     int place_spacer_gib = 0;           // ... the spacer that led to one last time
     float last_place_ratio = 0.f;       // ... two-stream / one-stream time of the pair handed out last (~1.3-1.45: different classes, ~2: one class)
@@ -82,6 +83,7 @@ struct sw_ctx {
     int64_t last_scouts = 0;            // scout workgroups of that launch
     int64_t last_xcd_mode = 0;          // that launch dealt its roles per XCD
     int64_t last_tiles = 1;             // column tiles (launches of the two-column kernel) of the last fill
+    int64_t last_split_from = 0;        // first strip whose scout also fills (split strips), 0: none
     bool xcd_round_robin = false;       // sw_xcc_probe saw workgroup i on XCD i % 8 (8 XCDs of 32 CUs)
     std::map<void*, void*> out_base;    // sw_alloc_outputs: pointer handed out -> allocation to free
 };
@@ -162,6 +164,8 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "batch_lds")) { c->opt_batch_lds = v < 0 ? 0 : v; return SW_OK; }
     if (!strcmp(name, "band_wait_ms")) { c->opt_band_wait_ms = v > 0 ? v : 20000; return SW_OK; }
     if (!strcmp(name, "placement_budget_ms")) { c->opt_place_budget_ms = v > 0 ? v : 200; return SW_OK; }
+    if (!strcmp(name, "split_blk")) { c->opt_split_blk = v > 0 ? v : 0; return SW_OK; }
+    if (!strcmp(name, "split_from")) { c->opt_split_from = v > 0 ? v : 0; return SW_OK; }
     if (!strcmp(name, "debug_epoch8")) { c->epoch8 = (unsigned)(v & 255); return SW_OK; }   // development aid: next launch tag = v + 1
     if (!strcmp(name, "engine")) {
         if (v != 0 && v != 1) { set_err("engine must be 0 (systolic) or 1 (strip_scan)"); return SW_EINVAL; }
@@ -193,6 +197,7 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "last_scouts")) return c->last_scouts;
     if (!strcmp(name, "last_xcd_mode")) return c->last_xcd_mode;
     if (!strcmp(name, "last_tiles")) return c->last_tiles;
+    if (!strcmp(name, "last_split_from")) return c->last_split_from;
     if (!strcmp(name, "xcd_round_robin")) return c->xcd_round_robin ? 1 : 0;
     if (!strcmp(name, "last_batch_kernel")) return c->last_batch_kernel;
     if (!strcmp(name, "placement_budget_ms")) return c->opt_place_budget_ms;
@@ -522,6 +527,43 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                     }
                     if (fits) { p2.xcd_mode = 1; p2.nscout = wg; p2.scout_double = dbl; grid2 = 256; }
                 }
+                // Split strips (sw_systolic2.inc): from strip split_from on -- those that would end after everybody else -- the strip's scout
+                // (a workgroup with rings and consumers then) writes the blocks from split_blk on and the filler only those before; the
+                // last strip gets a scout for it (one more workgroup on XCD 7).  The split point equalises the two ends: the filler needs
+                // tau_f per row, the scout ~21.5 ns before its consumers start and tau_f after.  Needs the per-XCD dealing and pacing (the
+                // common end every filler is paced to moves with it).  (debug bit 20: off)
+                p2.split_blk = 0; p2.split_from = 0; p2.split_extra = 0; p2.filler_end_steps = 0; p2.filler_full_steps = 0;
+                if (p2.xcd_mode == 1 && (rows >= 4096 || c->opt_split_blk > 0) && !j.d_top && !j.d_top_gran && !j.d_bot_gran && c->opt_filler_hop_ps > 0 &&
+                    !(c->opt_debug & (134217728 | 1048576))) {
+                    bool fits = true;
+                    int wg = 0, dbl = 0;
+                    for (int x = 0; x < 8 && fits; ++x) {
+                        const int nf = (int)(S2 / 8) + (x < (int)(S2 % 8) ? 1 : 0), ns = (x ? nf : nf - 1) + (x == 7 ? 1 : 0);
+                        const int ndx = std::max(0, ns - (32 - nf));
+                        fits = nf <= 31 && 2 * ndx <= ns;
+                        wg += ns - ndx; dbl += ndx;
+                    }
+                    const double hop = (double)c->opt_filler_hop_ps * 1e-12, tf = (double)c->opt_filler_tau_ps * 1e-12, ts = 21.5e-9;
+                    const int64_t nblk = (rows + 15) / 16;
+                    const int64_t sblk = (int64_t)((double)nblk * tf / (2.0 * tf - std::min(ts, tf)));
+                    const bool forced = c->opt_split_blk > 0;   // (tests: any split point, any first strip)
+                    if (fits && forced && c->opt_split_blk < nblk) {
+                        p2.split_blk = (int)c->opt_split_blk; p2.split_from = (int)std::max<int64_t>(1, c->opt_split_from); p2.split_extra = 1;
+                        p2.filler_end_steps = (int)((c->opt_split_blk * 16 + 126) / 64 * 64 + 64); p2.filler_full_steps = (int)((nblk * 16 + 126) / 64 * 64 + 64);
+                        p2.nscout = wg; p2.scout_double = dbl;
+                    } else if (fits && sblk >= 16 && sblk < nblk && rows >= 4096) {
+                        const int64_t full_steps = (nblk * 16 + 126) / 64 * 64 + 64, end_steps = (sblk * 16 + 126) / 64 * 64 + 64;
+                        // strip s, unsplit, would end s hand-offs + a whole strip after the start; the split ones end (S2 - 1) hand-offs + end_steps
+                        const double lead = ((double)full_steps - (double)end_steps) * tf / hop;
+                        const int64_t from = std::max<int64_t>(1, (int64_t)((double)(S2 - 1) - lead) + 1);
+                        if (from < S2) {
+                            p2.split_blk = (int)sblk; p2.split_from = (int)from; p2.split_extra = 1;
+                            p2.filler_end_steps = (int)end_steps; p2.filler_full_steps = (int)full_steps;
+                            p2.nscout = wg; p2.scout_double = dbl;
+                        }
+                    }
+                }
+                c->last_split_from = p2.split_blk ? p2.split_from : 0;
                 // The classic chain (no room for scouts), dealt per XCD the same way: neighbouring strips on one XCD, edge columns through
                 // its L2.  (option "xcd_chain": 0 auto, 1 on, 2 off)
                 if (!scouts && c->xcd_round_robin && grid2 >= 64 && !(c->opt_debug & 8388608) &&

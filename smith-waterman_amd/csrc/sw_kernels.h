@@ -73,6 +73,12 @@ struct FillParams {
     int final_launch;                    // the epilogue reports and re-arms the key (earlier tiles only accumulate into it)
     const unsigned char* alpha_a;        // what the prologue scans for letters: the WHOLE a (every tile must decide alike who fills)
     int64_t alpha_cols;
+    // split strips (round 4, xcd_mode 1): from strip split_from on, the filler of a strip writes only the 16-row blocks below split_blk and
+    // the strip's SCOUT -- a workgroup with rings and consumers like a filler -- writes the rest (sw_systolic2.inc); 0 = off
+    int split_blk, split_from;
+    int split_extra;                     // 1: the last strip has a scout workgroup too (it writes that strip's lower blocks; nobody reads its edge)
+    int filler_end_steps;                // pacing: the steps of the filler that ends last (a split one), 0 = every filler runs all steps
+    int filler_full_steps;               // pacing: steps of a whole strip (what the bandwidth bound is computed with)
 };
 constexpr int SW_XTAB_OFF = 448;         // atab + 448: unsigned int[256], XCD + 1 of every workgroup of the running sw_systolic2 launch (0: not there yet)
 constexpr int SW_PERM_PAD = -100;        // score of any cell outside the sequences (perm producer)

@@ -85,16 +85,21 @@ def test_other_alphabets_and_ties(engine, oracle):
 
 
 def test_more_strips_than_cus_streaming_checksums(engine, oracle, swamd):
-    """40000 x 4096: 318 strips of 126 columns, i.e. a second pass of the strip loop on a 256-CU device; per-row checksums and
-    arg-max against the streaming oracle."""
+    """40000 x 4096: 318 strips of 126 columns, i.e. a second pass of the strip loop on a 256-CU device -- or two column tiles; per-row
+    checksums and arg-max against the streaming oracle."""
     a, b = swamd.generate(40000, 4096, 3)
     st = oracle.fill_streaming(a, b)
-    out = engine.fill(a, b)
-    assert engine.get_option("last_strips2") == 318
-    r = out.result()
-    assert r["max_pos"] == st["max_pos"] and r["max_score"] == st["max_score"]
-    assert np.array_equal(engine.row_checksums(out.H), st["csH"]) and np.array_equal(engine.row_checksums(out.P), st["csP"])
-    assert np.array_equal(out.H[-1].cpu().numpy(), st["bottom"])
+    for flags, tiles, strips in ((524288, 1, 318), (0, 2, 159)):   # untiled (debug bit 19), then as the two column tiles the library picks since round 4
+        engine.set_option("debug_flags", flags)
+        try:
+            out = engine.fill(a, b)
+        finally:
+            engine.set_option("debug_flags", 0)
+        assert engine.get_option("last_tiles") == tiles and engine.get_option("last_strips2") == strips
+        r = out.result()
+        assert r["max_pos"] == st["max_pos"] and r["max_score"] == st["max_score"]
+        assert np.array_equal(engine.row_checksums(out.H), st["csH"]) and np.array_equal(engine.row_checksums(out.P), st["csP"])
+        assert np.array_equal(out.H[-1].cpu().numpy(), st["bottom"])
 
 
 @pytest.mark.parametrize("mode", ["p8", "p8_only", "p32_only", "h_only", "score_only"])

@@ -40,10 +40,20 @@ def test_xcd_layout_matches_oracle_and_plain_layout(engine, oracle, strips):
 def test_xcd_layout_limits(engine, oracle):
     """below 16 strips and where the scouts no longer fit (more than 1.5 x 168 workgroups) the plain layouts run"""
     _needs_round_robin(engine)
-    for strips, want in ((15, 0), (16, 1), (167, 1), (200, 0)):
+    for strips, want in ((15, 0), (16, 1), (167, 1)):
         a, b = oracle.generate(126 * strips, 64, 7)
         check_against_oracle(engine, oracle, a, b)
         assert engine.get_option("last_xcd_mode") == want, f"{strips} strips"
+    # 200 strips: two column tiles of 100 strips since round 4, each dealt per XCD; untiled (debug bit 19) the plain classic chain
+    a, b = oracle.generate(126 * 200, 64, 7)
+    check_against_oracle(engine, oracle, a, b)
+    assert engine.get_option("last_tiles") == 2 and engine.get_option("last_xcd_mode") == 1
+    engine.set_option("debug_flags", 524288)
+    try:
+        check_against_oracle(engine, oracle, a, b)
+        assert engine.get_option("last_tiles") == 1 and engine.get_option("last_xcd_mode") == 0
+    finally:
+        engine.set_option("debug_flags", 0)
 
 
 @pytest.mark.parametrize("mode", ["p8", "h64", "p8_only", "score_only"])
