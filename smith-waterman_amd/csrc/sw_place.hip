@@ -21,12 +21,36 @@ namespace swk {
 __global__ void __launch_bounds__(256) sw_two_stream_probe(unsigned char* __restrict__ X, unsigned char* __restrict__ Y, int64_t rows, int64_t pitch,
                                                            int seg_dw2, int nseg, int nrg, int mode, unsigned int val) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int seg = (int)blockIdx.x % nseg, rg = (int)blockIdx.x / nseg;
+    int seg = (int)blockIdx.x % nseg, rg = (int)blockIdx.x / nseg;
+    // experiments (mode bits): 16 = neighbouring segments on ONE XCD (workgroup b runs on XCD b % 8: segment = (b % 8) * per + b / 8, as the fill
+    // deals its strips), 32 = segment s starts s * lag later (the strips of a fill are a hand-off apart), 64 = the first / last 8 lanes
+    // (the pieces that share a 64-byte line with a neighbour) stored write-back, the others streaming
+    const int lag_ns = mode >> 8;
+    const bool grouped = mode & 16, lagged = mode & 32, edges_wb = mode & 64;
+    mode &= 15;
+    if (grouped) {
+        const int b = (int)blockIdx.x, nb = (int)gridDim.x, x = b & 7, k = b >> 3, per = (nseg + 7) / 8;
+        if (nb == nseg * nrg) { const int idx = x * ((nb + 7) / 8) + k; seg = idx % nseg; rg = idx / nseg; if (idx >= nb) return; (void)per; }
+    }
     if (lane >= seg_dw2) return;
+    if (lagged) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        const uint64_t wait = (uint64_t)seg * (uint64_t)lag_ns / 10u;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     const int64_t col = ((int64_t)seg * seg_dw2 + lane) * 8;
     const int64_t half = (rows / 2) * pitch;
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     const v2u v = {val, val + (unsigned)lane};
+    if (edges_wb) {
+        const bool edge = lane < 8 || lane >= seg_dw2 - 8;
+        for (int64_t r = rg + (int64_t)wave * nrg; r < rows; r += 4 * (int64_t)nrg) {
+            const int64_t o = r * pitch + col;
+            if (edge) { *(v2u*)(X + o) = v; *(v2u*)(Y + o) = v; }
+            else { __builtin_nontemporal_store(v, (v2u*)(X + o)); __builtin_nontemporal_store(v, (v2u*)(Y + o)); }
+        }
+        return;
+    }
     if (mode == 4) {   // two streams, write-back stores
         for (int64_t r = rg + (int64_t)wave * nrg; r < rows; r += 4 * (int64_t)nrg) {
             const int64_t o = r * pitch + col;
