@@ -294,6 +294,11 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       an unhindered strip (25000 ps), store bandwidth the strips share (4200 GB/s)
  *   "band_wait_ms"      sw_fill_band_device: how long a strip waits for its halo granules before the launch aborts
  *                       with SW_ETIMEOUT (default 20000)
+ *   "s2w"               two-column kernel: strips every 126 columns, or every 110 -- 126 wide, overlapping by 16 columns, so that every
+ *                       64-byte line of a matrix row lies inside one strip and is stored whole, by one instruction;
+ *                       0: the library chooses (110 for an int64 H with an int32 P beyond ~21 000 columns), 126 / 110 force one
+ *   "split_blk", "split_from"   two-column kernel behind scouts: from strip `split_from` on, the strip's scout writes the matrix
+ *                       blocks from `split_blk` on itself (0: the library chooses)
  *   "placement_budget_ms"  sw_alloc_outputs: how long the search for an H / P pair in different classes of the HBM may take (default 200)
  *   "max_blocks"        cap of the resident grid (0 = all CUs); concurrent band launches partition the CUs with it
  *   "waves_per_block", "debug_flags", "debug_buf", "batch_lds"   development aids (debug_flags 131072: no scout workgroups,

@@ -54,6 +54,7 @@ struct sw_ctx {
     unsigned int* d_part = nullptr;     // sw_prep_scan: one 256-bit presence map of byte values per block (up to 2048 blocks)
     unsigned int* d_sync = nullptr;     // one-launch fills (sw_systolic2's prologue / epilogue): barrier and exit counters, presence map; zero between launches
     unsigned char* d_priv = nullptr; size_t priv_cap = 0;   // ... and every workgroup's own padded copy of b + letter codes
+    int64_t opt_s2w = 0;                // two-column kernel: strips every 126 or 110 columns (overlapping strips, whole-line stores); 0: the library chooses
     int64_t opt_split_blk = 0, opt_split_from = 0;   // split strips: forced split block / first strip (0: chosen by the library; tests)
     int64_t opt_place_budget_ms = 200;  // sw_alloc_outputs: time the search for a P in another class of the HBM may take
     int place_spacer_gib = 0;           // ... the spacer that led to one last time
@@ -164,6 +165,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "batch_lds")) { c->opt_batch_lds = v < 0 ? 0 : v; return SW_OK; }
     if (!strcmp(name, "band_wait_ms")) { c->opt_band_wait_ms = v > 0 ? v : 20000; return SW_OK; }
     if (!strcmp(name, "placement_budget_ms")) { c->opt_place_budget_ms = v > 0 ? v : 200; return SW_OK; }
+    if (!strcmp(name, "s2w")) { if (v != 0 && v != 126 && v != 110) return SW_EINVAL; c->opt_s2w = v; return SW_OK; }
     if (!strcmp(name, "split_blk")) { c->opt_split_blk = v > 0 ? v : 0; return SW_OK; }
     if (!strcmp(name, "split_from")) { c->opt_split_from = v > 0 ? v : 0; return SW_OK; }
     if (!strcmp(name, "debug_epoch8")) { c->epoch8 = (unsigned)(v & 255); return SW_OK; }   // development aid: next launch tag = v + 1
@@ -450,7 +452,17 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         bool launched = false;
         c->last_strips2 = 0; c->last_scouts = 0; c->last_xcd_mode = 0; c->last_tiles = 1;
         if (two_cols) {
-            const int64_t S2all = (cols + 125) / 126;
+            // strip geometry: every 126 columns (the strips tile the matrix), or every 110 with 16 columns of overlap -- whole-line stores
+            // (sw_systolic2.inc); option "s2w" forces one of the two (tests, A/B runs)
+            const bool band_io = j.d_top || j.d_top_gran || j.d_bot_gran;
+            int64_t W2 = 126;
+            // (measured, 126 / 110, GCUPS: int64 H 16384^2 268 / 262, 24576^2 231 / 240, 32768^2 274 / 299, 49152^2 293 / 348, 65536^2 331..352 / 387..406;
+            //  int32 H 16384^2 330 / 306, 32768^2 388 / 362, 49152^2 420 / 409, 65536^2 438 / 426, 81920^2 454 / 463: the overlap costs 14 % more strips and
+            //  a dearer consumer, the whole lines win where the stores bound the fill -- an int64 H beyond the reach of the scouts)
+            const bool wl_fmt = !band_io && cols % 2 == 0 && j.d_H && j.d_P && j.p_elem_bytes == 4 && j.stride == cols + 1;
+            if (c->opt_s2w == 110 ? (!band_io && cols % 2 == 0) : (c->opt_s2w == 0 && wl_fmt && j.h_elem_bytes == 8 && (cols - 126 + 125) / 126 + 1 > 170)) W2 = 110;
+            auto strips_of = [&](int64_t ncols) { return ncols <= 126 ? (int64_t)1 : (ncols - 126 + W2 - 1) / W2 + 1; };
+            const int64_t S2all = strips_of(cols);
             // Column tiles.  Scout workgroups beside one filler per strip (sw_systolic2.inc) need 1.5 .. 2 workgroups per strip: up to ~170
             // strips (21 000 columns) on 256 CUs.  A wider matrix used to run the classic chain, fillers handing over to fillers at 7 us per
             // strip (32768^2: 349 GCUPS).  Now it is cut into column tiles of at most 160 strips, ONE LAUNCH EACH, every one with scouts,
@@ -471,12 +483,13 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             }
             c->last_tiles = ntile;
             for (int64_t tile = 0; tile < ntile; ++tile) {
-            const int64_t c0 = tile * tstrips * 126, tcols = std::min<int64_t>(cols - c0, tstrips * 126);
-            const int64_t S2 = (tcols + 125) / 126;
+            const int64_t c0 = tile * tstrips * W2, tcols = tile + 1 == ntile ? cols - c0 : tstrips * W2;   // (a tile owns tstrips * W2 columns; the last one the rest)
+            const int64_t S2 = strips_of(tcols);
             swk::FillParams p2 = p;
             p2.nstrips = (int)S2;
             p2.h_bytes = j.h_elem_bytes;
             p2.cols = tcols;
+            p2.s2w = (int)W2;
             if (ntile > 1) p2.store_nt = c->opt_store_policy == 2 || (c->opt_store_policy == 0 && (double)tcols * (double)rows <= 6.0e8);   // (per launch, as for a matrix of the tile's size)
             p2.alpha_a = ua; p2.alpha_cols = cols;
             p2.idx_off = c0; p2.final_launch = tile + 1 == ntile ? 1 : 0;

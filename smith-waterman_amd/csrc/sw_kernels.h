@@ -79,6 +79,10 @@ struct FillParams {
     int split_extra;                     // 1: the last strip has a scout workgroup too (it writes that strip's lower blocks; nobody reads its edge)
     int filler_end_steps;                // pacing: the steps of the filler that ends last (a split one), 0 = every filler runs all steps
     int filler_full_steps;               // pacing: steps of a whole strip (what the bandwidth bound is computed with)
+    // strip geometry of sw_systolic2: strip s spans the columns s2w * s + 1 .. s2w * s + 126 (63 lanes x 2); s2w = 126: the strips tile the
+    // matrix; s2w = 110: neighbouring strips OVERLAP by 16 columns, so that every 64-byte line of a matrix row lies wholly inside some
+    // strip and can be stored by ONE instruction of that strip (whole-line stores: sw_systolic2.inc).  0 is taken as 126.
+    int s2w;
 };
 constexpr int SW_XTAB_OFF = 448;         // atab + 448: unsigned int[256], XCD + 1 of every workgroup of the running sw_systolic2 launch (0: not there yet)
 constexpr int SW_PERM_PAD = -100;        // score of any cell outside the sequences (perm producer)

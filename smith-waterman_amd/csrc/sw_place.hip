@@ -25,14 +25,30 @@ __global__ void __launch_bounds__(256) sw_two_stream_probe(unsigned char* __rest
     // experiments (mode bits): 16 = neighbouring segments on ONE XCD (workgroup b runs on XCD b % 8: segment = (b % 8) * per + b / 8, as the fill
     // deals its strips), 32 = segment s starts s * lag later (the strips of a fill are a hand-off apart), 64 = the first / last 8 lanes
     // (the pieces that share a 64-byte line with a neighbour) stored write-back, the others streaming
-    const int lag_ns = mode >> 8;
+    const int mode0 = mode;
+    const int lag_ns = (mode & 128) ? 0 : mode >> 8;
     const bool grouped = mode & 16, lagged = mode & 32, edges_wb = mode & 64;
     mode &= 15;
     if (grouped) {
         const int b = (int)blockIdx.x, nb = (int)gridDim.x, x = b & 7, k = b >> 3, per = (nseg + 7) / 8;
         if (nb == nseg * nrg) { const int idx = x * ((nb + 7) / 8) + k; seg = idx % nseg; rg = idx / nseg; if (idx >= nb) return; (void)per; }
     }
-    if (lane >= seg_dw2) return;
+    if (mode0 & 128) {   // whole lines that start at lane k instead of lane 0 (k = bits 8..11; bit 12: k moves by one every second row)
+        const int k0 = (mode0 >> 8) & 15;
+        const bool vary = (mode0 >> 12) & 1;
+        typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+        const v2u v = {val, val + (unsigned)lane};
+        for (int64_t r = rg + (int64_t)wave * nrg; r < rows; r += 4 * (int64_t)nrg) {
+            const int k = vary ? (int)((k0 + (r >> 1)) & 7) : k0;
+            if (lane >= k && lane < k + seg_dw2) {
+                const int64_t o = r * pitch + ((int64_t)seg * seg_dw2 + lane - k) * 8;
+                __builtin_nontemporal_store(v, (v2u*)(X + o));
+                __builtin_nontemporal_store(v, (v2u*)(Y + o));
+            }
+        }
+        return;
+    }
+    if (lane >= seg_dw2 && mode != 8) return;
     if (lagged) {
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
         const uint64_t wait = (uint64_t)seg * (uint64_t)lag_ns / 10u;
@@ -42,6 +58,15 @@ __global__ void __launch_bounds__(256) sw_two_stream_probe(unsigned char* __rest
     const int64_t half = (rows / 2) * pitch;
     typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     const v2u v = {val, val + (unsigned)lane};
+    if (mode == 8) {   // the whole-line windows of overlapping strips: segment `seg` owns the lines that BEGIN inside its seg_dw2 * 8 bytes of the row
+        for (int64_t r = rg + (int64_t)wave * nrg; r < rows; r += 4 * (int64_t)nrg) {
+            const int64_t a0 = r * pitch + (int64_t)seg * seg_dw2 * 8 + 4, a1 = a0 + seg_dw2 * 8;
+            const int64_t l0 = (a0 + 63) & ~(int64_t)63, l1 = (a1 + 63) & ~(int64_t)63;
+            const int64_t o = l0 + lane * 8;
+            if (o < l1) { __builtin_nontemporal_store(v, (v2u*)(X + o)); __builtin_nontemporal_store(v, (v2u*)(Y + o)); }
+        }
+        return;
+    }
     if (edges_wb) {
         const bool edge = lane < 8 || lane >= seg_dw2 - 8;
         for (int64_t r = rg + (int64_t)wave * nrg; r < rows; r += 4 * (int64_t)nrg) {
