@@ -448,6 +448,7 @@ def main():
     ap.add_argument("--importers", type=int, default=0)
     ap.add_argument("--xcd-order", type=int, default=0, help="systolic: 1 = neighbouring strip groups on one XCD")
     ap.add_argument("--debug-flags", type=int, default=0)
+    ap.add_argument("--s2w", type=int, default=0, help="two-column kernel: strips every 126 or 110 columns (0: the library chooses)")
     ap.add_argument("--max-blocks", type=int, default=0)
     ap.add_argument("--batch-lds", type=int, default=0, help="batch kernel: dynamic LDS bytes per workgroup (caps the waves per CU; experiments)")
     ap.add_argument("--preheat", type=float, default=0.5, help="pair mode: seconds of untimed back-to-back fills before the warm-up steps")
@@ -492,7 +493,7 @@ def main():
         args.max_blocks = max(8, eng.get_option("num_cus") // -(-world // max(1, ndev)) - 16)
     eng.set_option("engine", args.engine)
     for name, v in (("importers", args.importers), ("store_policy", args.store_policy), ("strips_per_group", args.ns), ("consumers", args.nc),
-                    ("debug_flags", args.debug_flags), ("max_blocks", args.max_blocks), ("xcd_order", args.xcd_order), ("batch_lds", args.batch_lds)):
+                    ("debug_flags", args.debug_flags), ("max_blocks", args.max_blocks), ("xcd_order", args.xcd_order), ("batch_lds", args.batch_lds), ("s2w", args.s2w)):
         if v:
             eng.set_option(name, v)
     mode = args.mode

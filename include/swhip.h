@@ -251,10 +251,12 @@ int sw_row_checksums_device(sw_ctx* ctx, const void* d_X, int elem_bytes, int64_
  *                (csrc/sw_place.hip; ~0.3 ms per candidate, no fill of the caller's problem, d_a / d_b not needed); the first one in
  *                another class is kept (matrices of many GiB span classes themselves: 8 sample windows, the best of five candidates).
  *                Below 512 MiB of output a plain pair (such a fill is not bound by its stores).  The search runs against a time budget,
- *                option "placement_budget_ms" (default 200): fresh memory costs 0.3 ms per allocation, but memory that was in use
- *                before is wiped by the driver (~30 GiB/s) when it changes hands, and a spacer can then cost seconds; when the
- *                budget is spent the best candidate seen is handed out (sw_get_option "last_placement_ratio_x1000": ~1300-1450 =
- *                different classes, ~2000 = one class).  A caller that fills many times into the pair raises the budget.
+ *                option "placement_budget_ms" (default 1500): fresh memory costs 0.3 ms per allocation and the call takes 2-5 ms, but
+ *                memory that was in use before is wiped by the driver (~30 GiB/s) before it is handed out again, nothing tells
+ *                beforehand, and a spacer can then cost seconds -- so a spacer is tried only while its WORST case (40 ms per GiB)
+ *                still fits the budget (the default admits spacers up to 37 GiB), and when the budget is spent the best
+ *                candidate seen is handed out (sw_get_option "last_placement_ratio_x1000": ~1300-1450 = different classes,
+ *                ~2000 = one class).  A caller that fills many times into the pair raises the budget (bench.py: 20 s).
  *   trials == 1  a plain pair.
  *   trials  > 1  round 3's search: up to `trials` candidates, three fills of the caller's problem into each on the DEFAULT stream
  *                (d_a / d_b must be ready), the fastest kept.
@@ -299,7 +301,7 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       0: the library chooses (110 for an int64 H with an int32 P beyond ~21 000 columns), 126 / 110 force one
  *   "split_blk", "split_from"   two-column kernel behind scouts: from strip `split_from` on, the strip's scout writes the matrix
  *                       blocks from `split_blk` on itself (0: the library chooses)
- *   "placement_budget_ms"  sw_alloc_outputs: how long the search for an H / P pair in different classes of the HBM may take (default 200)
+ *   "placement_budget_ms"  sw_alloc_outputs: how long the search for an H / P pair in different classes of the HBM may take at worst (default 1500; 2-5 ms on memory that needs no wiping)
  *   "max_blocks"        cap of the resident grid (0 = all CUs); concurrent band launches partition the CUs with it
  *   "waves_per_block", "debug_flags", "debug_buf", "batch_lds"   development aids (debug_flags 131072: no scout workgroups,
  *                       8388608: scouts without the per-XCD dealing of the roles, 134217728: no pacing, 65536: batches on the

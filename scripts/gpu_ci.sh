@@ -14,14 +14,18 @@ step() {  # step <name> <timeout_s> <cmd...>
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a gpurun_out/ci.log; exit 1; fi
     return 0
 }
-: > gpurun_out/ci.log
+MODE="${1:-all}"    # all | tests | bench | prof  (a gpurun call is at most 20 minutes: tests, bench and prof are one call each)
+want() { [ "$MODE" = all ] || [ "$MODE" = "$1" ]; }
+[ "$MODE" = all ] || [ "$MODE" = tests ] && : > gpurun_out/ci.log
+echo "--- mode $MODE" >> gpurun_out/ci.log
 rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 >> gpurun_out/ci.log
 nproc >> gpurun_out/ci.log; lscpu | grep "Model name" >> gpurun_out/ci.log
 export TMPDIR=/tmp
-if [ "${1:-all}" != "profiles" ]; then
+if want tests; then
 step smoke 300 python __graft_entry__.py smoke
 step pytest_gpu 1100 python -m pytest tests -m gpu -x -q --durations=8
 fi
+if want bench; then
 # ---- BASELINE config 2 (the headline), with and without scouts / two columns per lane
 step bench 300 python bench.py
 step bench_no_pacing 200 python bench.py --steps 20 --warmup 3 --no-cpu --debug-flags 134217728
@@ -45,6 +49,8 @@ step bench_i32_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 6553
 step bench_i32_64k_untiled 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --debug-flags 524288
 # ---- config 3
 step bench_h64_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64
+step bench_h64_64k_strips_every_126 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64 --s2w 126
+step bench_i32_16k_strips_every_110 200 python bench.py --steps 20 --warmup 3 --no-cpu --s2w 110
 # ---- config 4 on one GPU: the per-rank shape of the 8-GPU run, the whole matrix P-only, two ranks rehearsing over gloo
 step bench_band_n8_shape_p8 500 python bench.py --mode bands --cols 262144 --rows 32768 --steps 3 --warmup 1 --p8
 step bench_config4_one_gpu_p_only 500 python bench.py --mode bands --cols 262144 --rows 262144 --p8 --no-h --steps 2 --warmup 1
@@ -60,6 +66,8 @@ step bench_batch_100k_old_path 400 python bench.py --mode batch --pairs 100000 -
 step ubench_scope 120 ./tools/ubench_scope
 step cli_16384 200 ./smith-waterman_amd/smithW 16384 16384
 step cli_2bands_1gpu_16384 200 ./smith-waterman_amd/smithW --devices 0,0 16384 16384
+fi
+if want prof; then
 # ---- rocprofv3: kernel trace + stats of the default bench and of the batch kernel
 rm -rf gpurun_out/prof gpurun_out/prof_batch gpurun_out/pmc
 step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python bench.py --steps 20 --warmup 3 --no-cpu
@@ -80,4 +88,5 @@ pmc batch_p8_WRITE_SIZE WRITE_SIZE --mode batch --pairs 20000 --steps 1 --warmup
 pmc batch_p8_FETCH_SIZE FETCH_SIZE --mode batch --pairs 20000 --steps 1 --warmup 1 --store --p8 --no-h
 # ---- placement: TCC write counters of the same fill into a same-class and a different-class pair
 step placement_pmc 400 bash scripts/gpu_placement_pmc.sh
+fi
 python3 scripts/collect_profiles.py gpurun_out | tee gpurun_out/profile_summary.log

@@ -56,7 +56,7 @@ struct sw_ctx {
     unsigned char* d_priv = nullptr; size_t priv_cap = 0;   // ... and every workgroup's own padded copy of b + letter codes
     int64_t opt_s2w = 0;                // two-column kernel: strips every 126 or 110 columns (overlapping strips, whole-line stores); 0: the library chooses
     int64_t opt_split_blk = 0, opt_split_from = 0;   // split strips: forced split block / first strip (0: chosen by the library; tests)
-    int64_t opt_place_budget_ms = 200;  // sw_alloc_outputs: time the search for a P in another class of the HBM may take
+    int64_t opt_place_budget_ms = 1500; // sw_alloc_outputs: time the search for a P in another class of the HBM may take
     int place_spacer_gib = 0;           // ... the spacer that led to one last time
     float last_place_ratio = 0.f;       // ... two-stream / one-stream time of the pair handed out last (~1.3-1.45: different classes, ~2: one class)
     bool key_dirty = false;             // d_key was left non-zero by a launch that does not re-arm it (everything but the one-launch fill)
@@ -164,7 +164,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "debug_buf")) { c->opt_dbg_ptr = v; return SW_OK; }
     if (!strcmp(name, "batch_lds")) { c->opt_batch_lds = v < 0 ? 0 : v; return SW_OK; }
     if (!strcmp(name, "band_wait_ms")) { c->opt_band_wait_ms = v > 0 ? v : 20000; return SW_OK; }
-    if (!strcmp(name, "placement_budget_ms")) { c->opt_place_budget_ms = v > 0 ? v : 200; return SW_OK; }
+    if (!strcmp(name, "placement_budget_ms")) { c->opt_place_budget_ms = v > 0 ? v : 1500; return SW_OK; }
     if (!strcmp(name, "s2w")) { if (v != 0 && v != 126 && v != 110) return SW_EINVAL; c->opt_s2w = v; return SW_OK; }
     if (!strcmp(name, "split_blk")) { c->opt_split_blk = v > 0 ? v : 0; return SW_OK; }
     if (!strcmp(name, "split_from")) { c->opt_split_from = v > 0 ? v : 0; return SW_OK; }
@@ -1033,23 +1033,27 @@ int sw_place_pair_ratio(void* d_X, size_t xbytes, void* d_Y, size_t ybytes, floa
 static int alloc_outputs_probed(sw_ctx* c, size_t hbytes, size_t pbytes, void** d_H, void** d_P, float* trial_ms, int ntrial_ms) {
     const size_t phase = 4u << 20;
     void* H = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     if (hipMalloc(&H, hbytes ? hbytes : 1) != hipSuccess) { (void)hipGetLastError(); set_err("sw_alloc_outputs: %zu bytes do not fit", hbytes); return SW_ENOMEM; }
+    // what a spacer can cost: 0.3 ms flat on fresh memory, 30-50 ms per GiB where the driver first wipes memory that was in use before (seen:
+    // 32 GiB in 0.2 ms, the next 64 GiB in 3.3 s) -- nothing tells beforehand, so a spacer is only tried while its worst case fits the budget
+    double ms_per_gib = 40.0;
     struct Cand { void* base; void* P; float ratio; };
     std::vector<Cand> cands;
     // Candidates for P: three plain ones (a class boundary may be right here), then behind temporary spacer allocations (taken only while
     // 8 GiB of head room remain, released as soon as the candidate behind them exists: the next spacer, of another size, then lands
     // elsewhere).  The classes are regions of 16 .. 120 GiB in the order the driver hands memory out.  What a spacer costs depends on the
     // box: memory that was in use before (by this or an earlier process) is wiped by the driver at ~30 GiB/s when it changes hands, fresh
-    // memory costs 0.3 ms per allocation -- so the search runs against a time budget (option "placement_budget_ms", default 200 ms; a
-    // caller that fills many times into the pair raises it) and settles for the best candidate seen when that is spent.  The spacer that
-    // worked is remembered per context and tried first next time.
+    // memory costs 0.3 ms per allocation -- so the search runs against a time budget (option "placement_budget_ms", default 1500 ms; a
+    // caller that fills many times into the pair raises it) and settles for the best candidate seen when that is spent; a spacer whose
+    // allocation alone could overrun the budget (at the wipe rate) is not tried: the default admits spacers up to 37 GiB.  The spacer that worked is
+    // remembered per context and tried first next time.
     static const int kSpacerGiB[14] = {0, 0, 0, 32, 64, 16, 96, 48, 128, 24, 80, 8, 160, 112};
     const bool debug = getenv("SW_PLACE_DEBUG") != nullptr;
     // (a matrix of many GiB spans several classes itself: more sample windows, and the best of a few candidates rather than the first good one)
     const bool big = std::max(hbytes, pbytes) > (6ull << 30);
     const float accept = big ? 1.40f : 1.5f;   // another class: ~1.3-1.45; the same class: ~2.0
-    const auto t0 = std::chrono::steady_clock::now();
-    auto elapsed_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     int best = -1, rc = SW_OK;
     for (int i = 0; i < 14; ++i) {
         int gib = kSpacerGiB[i];
@@ -1057,15 +1061,21 @@ static int alloc_outputs_probed(sw_ctx* c, size_t hbytes, size_t pbytes, void** 
         else if (i > 3 && gib == c->place_spacer_gib) continue;
         size_t sp = (size_t)gib << 30;
         if (sp && elapsed_ms() > (double)c->opt_place_budget_ms) break;
+        if (sp && elapsed_ms() + ms_per_gib * (double)gib > (double)c->opt_place_budget_ms) continue;   // (this spacer alone would overrun the budget: a smaller one may not)
         if (sp) {
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < sp + pbytes + (8ull << 30)) continue;   // not enough head room for this one
         }
         void* spacer = nullptr;
+        const double ts = elapsed_ms();
         if (sp && hipMalloc(&spacer, sp) != hipSuccess) { (void)hipGetLastError(); spacer = nullptr; continue; }
+        const double ts1 = elapsed_ms();
         Cand k = {nullptr, nullptr, 0.f};
         const hipError_t e = hipMalloc(&k.base, pbytes + phase);
+        const double ts2 = elapsed_ms();
         if (spacer) (void)hipFree(spacer);   // (it only steered where P landed)
+        if (sp) ms_per_gib = std::max(ms_per_gib, (elapsed_ms() - ts) / (double)gib);
+        if (debug) fprintf(stderr, "sw_alloc_outputs: spacer %d GiB: malloc %.1f ms, candidate malloc %.1f ms, free %.1f ms\n", gib, ts1 - ts, ts2 - ts1, elapsed_ms() - ts2);
         if (e != hipSuccess) { (void)hipGetLastError(); break; }
         // P two MiB out of phase with H modulo 4 MiB (round 1: neighbouring 2 MiB pages of the two streams)
         const uintptr_t want = ((uintptr_t)H + (2u << 20)) % phase;
