@@ -1,10 +1,12 @@
 # A/B of two builds of libswhip.so in ONE process on the SAME output buffers (placement moves a fill by 30 %: different processes cannot
-# be compared).  usage: python scripts/ab_libs.py <libA.so> <libB.so> [cols] [rows]
+# be compared).  usage: python scripts/ab_libs.py <libA.so> <libB.so> [more .so ...] [cols] [rows]
 import ctypes, importlib, sys, time, torch
 sys.path.insert(0, '.')
 sw = importlib.import_module("smith-waterman_amd")
-cols = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
-rows = int(sys.argv[4]) if len(sys.argv) > 4 else cols
+paths = [x for x in sys.argv[1:] if x.endswith(".so")]
+nums = [int(x) for x in sys.argv[1:] if not x.endswith(".so")]
+cols = nums[0] if nums else 16384
+rows = nums[1] if len(nums) > 1 else cols
 torch.cuda.init()
 a, b = sw.generate(cols, rows, 1)
 d_a = torch.zeros(cols + 16, dtype=torch.uint8, device="cuda"); d_a[:cols] = torch.from_numpy(a)
@@ -12,7 +14,7 @@ d_b = torch.zeros(rows + 16, dtype=torch.uint8, device="cuda"); d_b[:rows] = tor
 torch.cuda.synchronize()
 sc = sw._Scores(3, -3, -2)
 libs = []
-for path in sys.argv[1:3]:
+for path in paths:
     L = ctypes.CDLL(path)
     L.sw_last_error.restype = ctypes.c_char_p
     h = ctypes.c_void_p()

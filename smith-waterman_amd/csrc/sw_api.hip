@@ -399,7 +399,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         // The strict one-launch path needs a result to write (a batch keeps its own keys and never comes here).
         const int64_t priv_stride = ((2 * per + 255) / 256) * 256;
         if (two_cols) {
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, swk::sw_systolic2<6>, 768, 0));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, swk::sw_systolic2<6, false>, 768, 0));
             if (per_cu2 < 1 || !j.d_result) two_cols = false;
         }
         if (two_cols) {
@@ -600,10 +600,14 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 // consumer waves (+ 9 - nc2 importers).  Behind scouts a filler is never the one a hand-off waits for: two importers do, and seven
                 // consumers keep more stores in flight (16384^2 -1.5 %, 12288^2 -2.5 %, 20480^2 +-0 against five)
                 const int nc2 = c->opt_consumers == 0 ? (scouts ? 7 : (chain_bound ? 5 : 6)) : (int)std::min<int64_t>(7, c->opt_consumers);
-                if (nc2 == 7) hipLaunchKernelGGL(swk::sw_systolic2<7>, dim3(grid2), dim3(768), 0, stream, ua_t, ub, p2);
-                else if (nc2 == 6) hipLaunchKernelGGL(swk::sw_systolic2<6>, dim3(grid2), dim3(768), 0, stream, ua_t, ub, p2);
-                else if (nc2 == 5) hipLaunchKernelGGL(swk::sw_systolic2<5>, dim3(grid2), dim3(768), 0, stream, ua_t, ub, p2);
-                else hipLaunchKernelGGL(swk::sw_systolic2<4>, dim3(grid2), dim3(768), 0, stream, ua_t, ub, p2);
+                auto launch2 = [&](auto nc, auto ov) { hipLaunchKernelGGL((swk::sw_systolic2<decltype(nc)::value, decltype(ov)::value>), dim3(grid2), dim3(768), 0, stream, ua_t, ub, p2); };
+                auto launch_nc = [&](auto ov) {
+                    if (nc2 == 7) launch2(std::integral_constant<int, 7>{}, ov);
+                    else if (nc2 == 6) launch2(std::integral_constant<int, 6>{}, ov);
+                    else if (nc2 == 5) launch2(std::integral_constant<int, 5>{}, ov);
+                    else launch2(std::integral_constant<int, 4>{}, ov);
+                };
+                if (W2 == 110) launch_nc(std::true_type{}); else launch_nc(std::false_type{});   // (the strip geometry is compiled in)
                 c->last_strips2 = S2;
             }
             }   // (tiles)

@@ -112,7 +112,7 @@ __global__ void sw_strip_scan(const unsigned char* a, const unsigned char* b, Fi
 template <typename HT, int NS, int NC>
 __global__ void sw_systolic(const unsigned char* a, const unsigned char* b, const unsigned char* bpad, FillParams p);
 __global__ void sw_wipe_u32(unsigned int* buf, size_t n);
-template <int NC>
+template <int NC, bool OV>
 __global__ void sw_systolic2(const unsigned char* a, const unsigned char* b, FillParams p);
 __global__ void sw_prep_scan(const unsigned char* a, int64_t cols, int64_t a_pstride, const unsigned char* b, int64_t rows, int64_t b_pstride, int64_t npairs,
                              unsigned int* part);
