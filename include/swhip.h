@@ -266,6 +266,12 @@ int sw_row_checksums_device(sw_ctx* ctx, const void* d_X, int elem_bytes, int64_
 int sw_alloc_outputs(sw_ctx* ctx, const char* d_a, int64_t cols, const char* d_b, int64_t rows, const sw_scores* scores,
                      int h_elem_bytes, int p_elem_bytes, int trials, void** d_H, void** d_P, float* trial_ms);
 int sw_free_outputs(sw_ctx* ctx, void* d_H, void* d_P);
+/* The classifier of sw_alloc_outputs for buffers the caller allocated itself: how much slower two store streams into (d_X, d_Y) run
+ * together than one stream into d_X alone -- *ratio ~1.3-1.45: the two lie in different classes of the HBM, ~2.0: in the same one (a fill
+ * that writes H into one and P into the other is then ~1.3x slower).  Samples windows of up to 128 MiB (8 of them for buffers of more
+ * than 6 GiB) and WRITES them: call it before the buffers hold anything.  Runs on the current device, default stream, ~0.2 ms per window;
+ * ms_together (optional): the time of the two-stream probe. */
+int sw_place_pair_ratio(void* d_X, size_t xbytes, void* d_Y, size_t ybytes, float* ratio, float* ms_together);
 
 /* ---- device memory plumbing for hosts without a HIP binding (cgo / JNI / ctypes callers) --- */
 int sw_device_malloc(sw_ctx* ctx, size_t bytes, void** d_ptr);

@@ -45,13 +45,14 @@ def counters(tag, kernel_substr):
 
 
 print("== bench lines")
-_steps = [ln[4:].strip() for ln in open(os.path.join(src, "ci.log")) if ln.startswith("=== ")] if os.path.exists(os.path.join(src, "ci.log")) else None
+_cilogs = [f for f in (os.path.join(src, f"ci_{m}.log") for m in ("all", "tests", "bench", "prof")) if os.path.exists(f)]
+_steps = [ln[4:].strip() for f in _cilogs for ln in open(f) if ln.startswith("=== ")] if _cilogs else None
 for f in sorted(glob.glob(os.path.join(src, "bench*.log"))):
     d = bench_line(f)
     if d and (_steps is None or os.path.basename(f)[:-4] in _steps):
         r = d.get("roofline", {})
-        print(f"{os.path.basename(f)[:-4]:36s} {d['value']:9.1f} {d['unit']}  {d['ms_per_step']:9.4f} ms/step  n_gpus {d['n_gpus']}  "
-              f"frac {r.get('frac', 0):.3f} ({r.get('bound', '-')})  tau {r.get('tau_step_ns', 0) or 0:.1f} ns  lag {r.get('strip_handoff_lag_ns', 0) or 0:.0f} ns")
+        print(f"{os.path.basename(f)[:-4]:36s} {d['value'] or 0:9.1f} {d['unit']}  {d['ms_per_step'] or 0:9.4f} ms/step  n_gpus {d['n_gpus']}  "
+              f"frac {r.get('frac') or 0:.3f} ({r.get('bound', '-')})  tau {r.get('tau_step_ns', 0) or 0:.1f} ns  lag {r.get('strip_handoff_lag_ns', 0) or 0:.0f} ns")
 
 print("== rocprofv3 kernel stats (top kernels)")
 for d in ("prof", "prof_batch"):
@@ -108,13 +109,14 @@ json.dump(out, open(os.path.join(src, "r04_pmc_traffic.json"), "w"), indent=1)
 if copy:
     os.makedirs(prof, exist_ok=True)
     n = 0
-    steps = [ln[4:].strip() for ln in open(os.path.join(src, "ci.log")) if ln.startswith("=== ")]   # only what THIS run produced
+    steps = _steps or []   # only what THIS run's stages produced
+    open(os.path.join(prof, "r04_ci.log"), "w").write("".join(open(f).read() for f in _cilogs))
     for f in sorted(glob.glob(os.path.join(src, "bench*.log"))):
         d = bench_line(f)
         if d and os.path.basename(f)[:-4] in steps:
             json.dump(d, open(os.path.join(prof, "r04_" + os.path.basename(f)[:-4] + ".json"), "w"))
             n += 1
-    for name, dst in (("ci.log", "r04_ci.log"), ("profile_summary.log", "r04_profile_summary.log"), ("r04_pmc_traffic.json", "r04_pmc_traffic.json"),
+    for name, dst in (("profile_summary.log", "r04_profile_summary.log"), ("r04_pmc_traffic.json", "r04_pmc_traffic.json"),
                       ("cli_16384.log", "r04_cli.log"), ("cli_2bands_1gpu_16384.log", "r04_cli_2bands_1gpu.log"), ("pytest_gpu.log", "r04_pytest_gpu.log"),
                       ("ubench_scope.log", "r04_ubench_scope.log"), ("pmc/placement_summary.json", "r04_placement_tcc_counters_same_vs_different_class.json")):
         if os.path.exists(os.path.join(src, name)):

@@ -6,20 +6,20 @@ set -u
 mkdir -p gpurun_out
 step() {  # step <name> <timeout_s> <cmd...>
     local name=$1 to=$2; shift 2
-    echo "=== $name" | tee -a gpurun_out/ci.log
+    echo "=== $name" | tee -a "$CILOG"
     timeout -k 10 "$to" "$@" > "gpurun_out/$name.log" 2>&1
     local rc=$?
-    echo "$name rc=$rc" | tee -a gpurun_out/ci.log
+    echo "$name rc=$rc" | tee -a "$CILOG"
     tail -n 2 "gpurun_out/$name.log" | cut -c1-400
-    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a gpurun_out/ci.log; exit 1; fi
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a "$CILOG"; exit 1; fi
     return 0
 }
 MODE="${1:-all}"    # all | tests | bench | prof  (a gpurun call is at most 20 minutes: tests, bench and prof are one call each)
 want() { [ "$MODE" = all ] || [ "$MODE" = "$1" ]; }
-[ "$MODE" = all ] || [ "$MODE" = tests ] && : > gpurun_out/ci.log
-echo "--- mode $MODE" >> gpurun_out/ci.log
-rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 >> gpurun_out/ci.log
-nproc >> gpurun_out/ci.log; lscpu | grep "Model name" >> gpurun_out/ci.log
+CILOG="gpurun_out/ci_$MODE.log"      # (one log per stage: gpurun merges a call's files over the earlier ones of the same name)
+echo "--- stage $MODE, $(date -u +%FT%TZ)" > "$CILOG"
+rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 >> "$CILOG"
+nproc >> "$CILOG"; lscpu | grep "Model name" >> "$CILOG"
 export TMPDIR=/tmp
 if want tests; then
 step smoke 300 python __graft_entry__.py smoke

@@ -84,6 +84,7 @@ ABI = {
     "sw_alloc_outputs": (_i32, [_vp, _vp, _i64, _vp, _i64, ctypes.POINTER(_Scores), _i32, _i32, _i32, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                 ctypes.POINTER(ctypes.c_float)]),
     "sw_free_outputs": (_i32, [_vp, _vp, _vp]),
+    "sw_place_pair_ratio": (_i32, [_vp, _sz, _vp, _sz, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]),
     "sw_device_malloc": (_i32, [_vp, _sz, ctypes.POINTER(_vp)]),
     "sw_device_free": (_i32, [_vp, _vp]),
     "sw_memcpy_h2d": (_i32, [_vp, _vp, _vp, _sz]),
