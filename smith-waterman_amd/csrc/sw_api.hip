@@ -809,8 +809,9 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
         const int pb = d_P ? p_elem_bytes : 0;
         if (packed16 && n >= 2) {
             const dim3 grid16((unsigned)(((n + 1) / 2 + 3) / 4)), block16(256);   // 4 waves = 8 pairs per workgroup
-            if (nletters <= 4u) hipLaunchKernelGGL(swk::sw_batch_wave16<true>, grid16, block16, 0, stream, bp);
-            else hipLaunchKernelGGL(swk::sw_batch_wave16<false>, grid16, block16, 0, stream, bp);
+            const bool k12 = (int64_t)sc->match * std::min(cols, rows) < 4096;   // (scores of 12 bits: the arg-max runs on score * 16 + column keys)
+            if (nletters <= 4u) { if (k12) hipLaunchKernelGGL((swk::sw_batch_wave16<true, true>), grid16, block16, 0, stream, bp); else hipLaunchKernelGGL((swk::sw_batch_wave16<true, false>), grid16, block16, 0, stream, bp); }
+            else { if (k12) hipLaunchKernelGGL((swk::sw_batch_wave16<false, true>), grid16, block16, 0, stream, bp); else hipLaunchKernelGGL((swk::sw_batch_wave16<false, false>), grid16, block16, 0, stream, bp); }
             HIP_TRY(hipGetLastError());
             c->last_batch_kernel = 2;
             continue;

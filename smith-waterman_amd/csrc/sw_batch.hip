@@ -351,6 +351,7 @@ __device__ __forceinline__ u32 pk_max_i16(u32 a, u32 b) { u32 d; SB_PK2("v_pk_ma
 __device__ __forceinline__ u32 pk_sub_u16(u32 a, u32 b) { u32 d; SB_PK2("v_pk_sub_u16", d, a, b); return d; }             // wraps
 __device__ __forceinline__ u32 pk_subs_u16(u32 a, u32 b) { u32 d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }   // saturates at 0
 __device__ __forceinline__ u32 pk_mad_u16(u32 a, u32 b, u32 c) { u32 d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ u32 pk_mad_u16_sc(u32 a, u32 b, u32 c) { u32 d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c)); return d; }   // c: a wave-uniform constant (SGPR)
 // t = {dprev.lo + sext(SA.byte J), dprev.hi + sext(SB.byte J)}
 template <int J>
 __device__ __forceinline__ u32 pk_add_sbytes(u32 dprev, u32 SA, u32 SB) {
@@ -391,7 +392,10 @@ __device__ __forceinline__ u32 pk_cell(u32 dprev, u32 SA, u32 SB, u32 old, u32 p
 }
 
 // C = 16 columns per lane; LE4: the batch has at most 4 distinct letters (codes 0..3: the upper half of the score profiles is never selected)
-template <bool LE4>
+// K12: every score is below 4096 (match * min(cols, rows) < 2^12: 1024^2 with match 3), so score * 16 + (15 - column) fits a half: the tree of
+// row maxima runs on these KEYS and its root already names the first column that holds the maximum -- 16 v_pk_mad_u16 instead of the
+// 33-instruction descent (132 against 149.5 VALU per step)
+template <bool LE4, bool K12>
 __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams p) {   // (LE4: 4 waves per SIMD, at most 128 VGPRs)
     constexpr int C = 16;
     const int lane = threadIdx.x & 63;
@@ -411,7 +415,7 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
                                                                         multi ? (int)(p.bnd_pstride * 4) : 0, 0x00020000);   // (the couple shares pair A's boundary row: packed values)
     const u32 mis4 = 0x01010101u * (u32)(unsigned char)(signed char)p.mismatch;
     const u32 dmm = ((u32)(unsigned char)(signed char)p.match) ^ ((u32)(unsigned char)(signed char)p.mismatch);
-    const u32 gg = (u32)p.ngap * 0x00010001u, one2 = 0x00010001u;
+    const u32 gg = (u32)p.ngap * 0x00010001u, one2 = 0x00010001u, sixteen2 = 0x00100010u;
     u64 kbestA = 0, kbestB = 0;
     const int G = (rows + 64 + 3) / 4;
 
@@ -476,6 +480,22 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
                 });
                 if (bw) __builtin_amdgcn_raw_buffer_store_b32((int)h[C - 1], rB, lane == 63 ? 4 : (int)SB_OOB, 4 * u, 0);   // row u - 63 at index row + 64
                 // ---- arg-max: tree of row maxima, first column that holds the maximum, strict update of the lane's record
+                auto sel = [&](u32 b, u32 x, u32 y) { return pk_mad_u16(b, pk_sub_u16(y, x), x); };    // b ? y : x  (b = 0 / 1 per half)
+                const u32 upk = (u32)__builtin_amdgcn_readfirstlane(u * 0x00010001);
+                if constexpr (K12) {
+                    // keys: score * 16 + (15 - column): the maximum key is the highest score in its lowest column; lbest holds the lane's best KEY
+                    u32 n1[8], n2[4];
+                    sb_for<0, 8>([&](auto I) {
+                        constexpr int i = decltype(I)::value;
+                        n1[i] = pk_max_u16(pk_mad_u16_sc(h[2 * i], sixteen2, (u32)(15 - 2 * i) * 0x00010001u), pk_mad_u16_sc(h[2 * i + 1], sixteen2, (u32)(14 - 2 * i) * 0x00010001u));
+                    });
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) n2[i] = pk_max_u16(n1[2 * i], n1[2 * i + 1]);
+                    const u32 m = pk_max_u16(pk_max_u16(n2[0], n2[1]), pk_max_u16(n2[2], n2[3]));
+                    const u32 imp = pk_min_u16(pk_subs_u16(m, lbest | 0x000F000Fu), one2);          // 1 where the SCORE beats the lane's best so far
+                    lbest = sel(imp, lbest, m);
+                    lstep = sel(imp, lstep, upk);
+                } else {
                 u32 n1[8], n2[4], n3[2];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) n1[i] = pk_max_u16(h[2 * i], h[2 * i + 1]);
@@ -487,7 +507,6 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
                 // (tried: the search only in steps that reach the pair's best so far, behind a wave-uniform threshold -- 7214 against 7170
                 //  GCUPS: some lane of the 64 is near its pair's best in almost every step, the branch saves next to nothing)
                 auto isnot = [&](u32 node) { return pk_min_u16(pk_sub_u16(m, node), one2); };
-                auto sel = [&](u32 b, u32 x, u32 y) { return pk_mad_u16(b, pk_sub_u16(y, x), x); };
                 const u32 b3 = isnot(n3[0]);
                 const u32 b2 = isnot(sel(b3, n2[0], n2[2]));
                 const u32 b1 = isnot(sel(b3, sel(b2, n1[0], n1[2]), sel(b2, n1[4], n1[6])));
@@ -495,10 +514,10 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
                 const u32 two2 = 0x00020002u;
                 const u32 kk = pk_mad_u16(pk_mad_u16(pk_mad_u16(b3, two2, b2), two2, b1), two2, b0);   // 8 b3 + 4 b2 + 2 b1 + b0
                 const u32 imp = pk_min_u16(pk_subs_u16(m, lbest), one2);                              // 1 where m > the lane's best so far
-                const u32 upk = (u32)__builtin_amdgcn_readfirstlane(u * 0x00010001);
                 lbest = pk_max_u16(lbest, m);
                 lk = sel(imp, lk, kk);
                 lstep = sel(imp, lstep, upk);
+                }
             });
         }
         {
@@ -509,8 +528,13 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
                     kb = key > kb ? key : kb;
                 }
             };
-            rec(lbest & 0xffffu, lstep & 0xffffu, lk & 0xffffu, kbestA);
-            rec(lbest >> 16, lstep >> 16, lk >> 16, kbestB);
+            if constexpr (K12) {
+                rec((lbest & 0xffffu) >> 4, lstep & 0xffffu, 15u - (lbest & 15u), kbestA);
+                rec(lbest >> 20, lstep >> 16, 15u - ((lbest >> 16) & 15u), kbestB);
+            } else {
+                rec(lbest & 0xffffu, lstep & 0xffffu, lk & 0xffffu, kbestA);
+                rec(lbest >> 16, lstep >> 16, lk >> 16, kbestB);
+            }
         }
     }
     // each pair's arg-max: highest score, lowest linear index among equals (serial_smithW.c:240-242)
@@ -537,8 +561,10 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
         }
     }
 }
-template __global__ void sw_batch_wave16<true>(BatchParams);
-template __global__ void sw_batch_wave16<false>(BatchParams);
+template __global__ void sw_batch_wave16<true, true>(BatchParams);
+template __global__ void sw_batch_wave16<true, false>(BatchParams);
+template __global__ void sw_batch_wave16<false, true>(BatchParams);
+template __global__ void sw_batch_wave16<false, false>(BatchParams);
 
 #define SB_INST(C, PB) template __global__ void sw_batch_wave<C, PB>(BatchParams);
 SB_INST(4, 0) SB_INST(4, 1) SB_INST(4, 4) SB_INST(8, 0) SB_INST(8, 1) SB_INST(8, 4) SB_INST(16, 0) SB_INST(16, 1) SB_INST(16, 4)

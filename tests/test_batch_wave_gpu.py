@@ -178,3 +178,16 @@ def test_packed16_falls_back_when_scores_need_more_than_15_bits(engine, oracle):
     _check16(engine, oracle, A, B, scores=(40, -3, -2), expect=1)
     A, B = _pairs(np.random.default_rng(6), 1, 1024, 100)   # a single pair has nobody to share a wave with
     _check16(engine, oracle, A, B, expect=1)
+
+
+@pytest.mark.parametrize("match,cols,rows,expect_k12", [(3, 1024, 1024, True), (3, 1365, 1365, True), (3, 1366, 1366, False), (4, 1024, 1024, False), (7, 600, 585, True), (7, 600, 586, False)])
+def test_packed16_keyed_argmax_up_to_12_bit_scores(engine, oracle, match, cols, rows, expect_k12):
+    """match x min(cols, rows) < 4096: the arg-max tree runs on score x 16 + column keys; at and above the limit on plain scores with a descent.
+    Either way the same result -- the all-match pair reaches the highest score the shape allows (4095 at the edge), periodic pairs tie in
+    many columns of a lane and many rows"""
+    assert (match * min(cols, rows) < 4096) == expect_k12
+    A, B = _pairs(np.random.default_rng(match * cols + rows), 6, cols, rows)
+    A[1], B[1] = 65, 65                                   # all-match
+    A[2] = np.resize(np.frombuffer(b"ACGT", np.uint8), cols); B[2] = np.resize(np.frombuffer(b"ACGT", np.uint8), rows)
+    A[3] = np.resize(np.frombuffer(b"AACC", np.uint8), cols); B[3] = np.resize(np.frombuffer(b"AC", np.uint8), rows)
+    _check16(engine, oracle, A, B, scores=(match, -3, -2))
