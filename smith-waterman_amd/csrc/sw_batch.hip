@@ -25,6 +25,9 @@ typedef unsigned int u32;
 typedef unsigned long long u64;
 
 constexpr u32 SB_OOB = 0xFFFFFF00u;
+#ifndef SB_RUN16
+#define SB_RUN16 512                       // the same for the packed kernel with P (two-bit rings: 16 KB per wave)
+#endif
 #ifndef SB_RUN
 #define SB_RUN 256                         // bytes of one row that a lane group stores with one instruction (int8 P)
 #endif      // buffer offset beyond every descriptor: the store is dropped
@@ -381,6 +384,35 @@ __device__ __forceinline__ u32 pk_add_sbytes(u32 dprev, u32 SA, u32 SB) {
         "v_pk_sub_u16 %1, %1, %8 clamp\n\t"                                                                                           \
         "v_pk_max_i16 %2, %0, %1"                                                                                                     \
         : "=&v"(t), "=&v"(u2), "=v"(hn) : "v"(dprev), "v"(SA), "v"(SB), "v"(old), "v"(prev), "v"(gg))
+__device__ __forceinline__ u32 pk_mad_u16_sb(u32 a, u32 b, u32 c) { u32 d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c)); return d; }   // b: a wave-uniform constant (SGPR)
+// the cell AND its P code (serial_smithW.c:187-256: DIAGONAL before UP before LEFT, NONE where H = 0) for both pairs, without a compare:
+//     e = min(u2 - old, 1)   0: UP attains max(up, left)          d = min(H - t, 1)   0: the diagonal term attains H        z = min(H, 1)
+//     code = z * (3 + d * (e - 2))     ->  3 (d = 0), 1 (d = 1, e = 0), 2 (d = 1, e = 1), 0 (H = 0)
+// 13 instructions for two cells, one statement
+#define SB_PK_CELL_P(BYTE)                                                                                                            \
+    asm("v_add_u32_sdwa %0, %4, sext(%5) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:" BYTE "\n\t"                    \
+        "v_pk_max_u16 %1, %7, %8\n\t"                                                                                                 \
+        "v_add_u32_sdwa %0, %4, sext(%6) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:" BYTE "\n\t"               \
+        "v_pk_sub_u16 %3, %1, %7\n\t"                                                                                                 \
+        "v_pk_sub_u16 %1, %1, %9 clamp\n\t"                                                                                           \
+        "v_pk_min_u16 %3, %3, %10\n\t"                                                                                                \
+        "v_pk_max_i16 %2, %0, %1\n\t"                                                                                                 \
+        "v_pk_sub_u16 %3, %3, %11\n\t"                                                                                                \
+        "v_pk_sub_u16 %0, %2, %0\n\t"                                                                                                 \
+        "v_pk_min_u16 %1, %2, %10\n\t"                                                                                                \
+        "v_pk_min_u16 %0, %0, %10\n\t"                                                                                                \
+        "v_pk_mad_u16 %0, %0, %3, %12\n\t"                                                                                            \
+        "v_pk_mul_lo_u16 %3, %0, %1"                                                                                                  \
+        : "=&v"(t), "=&v"(u2), "=&v"(hn), "=&v"(code) : "v"(dprev), "v"(SA), "v"(SB), "v"(old), "v"(prev), "v"(gg), "v"(one2), "v"(two2), "s"(0x00030003u))
+template <int J>
+__device__ __forceinline__ u32 pk_cell_p(u32 dprev, u32 SA, u32 SB, u32 old, u32 prev, u32 gg, u32 one2, u32 two2, u32& code) {
+    u32 t, u2, hn;
+    if constexpr (J == 0) SB_PK_CELL_P("BYTE_0");
+    else if constexpr (J == 1) SB_PK_CELL_P("BYTE_1");
+    else if constexpr (J == 2) SB_PK_CELL_P("BYTE_2");
+    else SB_PK_CELL_P("BYTE_3");
+    return hn;
+}
 template <int J>
 __device__ __forceinline__ u32 pk_cell(u32 dprev, u32 SA, u32 SB, u32 old, u32 prev, u32 gg) {
     u32 t, u2, hn;
@@ -395,9 +427,16 @@ __device__ __forceinline__ u32 pk_cell(u32 dprev, u32 SA, u32 SB, u32 old, u32 p
 // K12: every score is below 4096 (match * min(cols, rows) < 2^12: 1024^2 with match 3), so score * 16 + (15 - column) fits a half: the tree of
 // row maxima runs on these KEYS and its root already names the first column that holds the maximum -- 16 v_pk_mad_u16 instead of the
 // 33-instruction descent (132 against 149.5 VALU per step)
-template <bool LE4, bool K12>
-__global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams p) {   // (LE4: 4 waves per SIMD, at most 128 VGPRs)
+// PB1: the predecessor matrices of both pairs are written too, one byte per cell.  The codes come out of packed arithmetic (SB_PK_CELL_P).  As in
+// sw_batch_wave a lane's piece of a row waits in an LDS ring until the 16 lanes of its group can store 256 contiguous bytes of ONE row with
+// one instruction -- but the ring holds the codes at TWO BITS each (4 + 4 bytes per lane and row for the two pairs: 8 KB per wave, so that
+// two waves per SIMD fit; with byte rings the kernel ran one wave per SIMD and lost to its own latencies: 2400 GCUPS against 3700 with the
+// stores dropped; with 128-byte runs and two waves per SIMD 1940).  Byte j of a packed word holds the codes of columns j, j + 4, j + 8, j + 12,
+// so (w >> 2k) & 0x03030303 IS output dword k.
+template <bool LE4, bool K12, bool PB1>
+__global__ void __launch_bounds__(256, PB1 ? 2 : (LE4 ? 4 : 3)) sw_batch_wave16(BatchParams p) {   // (LE4 score-only: 4 waves per SIMD, at most 128 VGPRs)
     constexpr int C = 16;
+    constexpr int RUN = PB1 ? SB_RUN16 : 256;   // bytes of one row that a lane group stores with one instruction
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t couple = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -415,9 +454,15 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
                                                                         multi ? (int)(p.bnd_pstride * 4) : 0, 0x00020000);   // (the couple shares pair A's boundary row: packed values)
     const u32 mis4 = 0x01010101u * (u32)(unsigned char)(signed char)p.mismatch;
     const u32 dmm = ((u32)(unsigned char)(signed char)p.match) ^ ((u32)(unsigned char)(signed char)p.mismatch);
-    const u32 gg = (u32)p.ngap * 0x00010001u, one2 = 0x00010001u, sixteen2 = 0x00100010u;
+    const u32 gg = (u32)p.ngap * 0x00010001u, one2 = 0x00010001u, sixteen2 = 0x00100010u, two2 = 0x00020002u;
     u64 kbestA = 0, kbestB = 0;
-    const int G = (rows + 64 + 3) / 4;
+    const int G = (rows + 64 + (PB1 ? RUN / C + 1 : 0) + 3) / 4;   // (delayed P stores drain for up to RUN / C + 1 more steps)
+    const int pbytes = PB1 ? (int)((int64_t)(rows + 1) * M) : 0;
+    const __amdgpu_buffer_rsrc_t rPA = __builtin_amdgcn_make_buffer_rsrc((void*)(PB1 ? (char*)p.P + pairA * p.hp_pstride : nullptr), 0, pbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rPB = __builtin_amdgcn_make_buffer_rsrc((void*)(PB1 ? (char*)p.P + pairB * p.hp_pstride : nullptr), 0, pairB != pairA ? pbytes : 0, 0x00020000);
+    const bool ragged = (cols % C) != 0;
+    __shared__ __attribute__((aligned(16))) unsigned char sb_ring16[PB1 ? 4 * (RUN / C) * 64 * 8 : 16];   // per wave: 16 slots x 64 lanes x (4 + 4) bytes
+    unsigned char* const ring = sb_ring16 + (PB1 ? wave * (RUN / C) * 64 * 8 + lane * 8 : 0);
 
     for (int st = 0; st < nstrips; ++st) {
         const int c0 = st * 64 * C + lane * C + 1;
@@ -441,6 +486,17 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
         for (int k = 0; k < C; ++k) h[k] = 0u;
         u32 diag0 = 0u, lbest = 0u, lk = 0u, lstep = 0u;
         const bool bw = multi && st + 1 < nstrips, br = multi && st > 0;
+        // P stores (PB1): as in sw_batch_wave -- my piece of row u - lane leaves 1 + dly steps late, so that the 16 lanes of a group store
+        // 256 contiguous bytes of ONE row per instruction
+        const int nval = min(C, max(0, cols - c0 + 1));
+        const bool full = PB1 && nval == C && !(p.debug & 1);
+        constexpr int GS = RUN / C;
+        const int dly = GS - 1 - (lane & (GS - 1)), dslot = (GS - dly) & (GS - 1);
+        u32 voffP = full ? (u32)(-lane * M + c0) - (u32)((1 + dly) * M) : SB_OOB;
+        const bool col0 = PB1 && st == 0 && lane == 0;
+        u32 voffP0 = col0 ? 0u : SB_OOB;
+        const u32 pitchP = full ? (u32)M : 0u, pitchP0 = col0 ? (u32)M : 0u;
+        sb_v2i dw = {0, 0};        // the delayed row's codes, two bits each: .x pair A, .y pair B
         sb_v4i bq = {0, 0, 0, 0};
         const u32 voffB = lane == 0 ? 64u * 4u : SB_OOB;
         if (br) {
@@ -470,14 +526,48 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
                 const u32 left = (u32)sb_dpp_shr1(br ? bcur[j] : 0, (int)h[C - 1]);
                 u32 dprev = diag0, prev = left;
                 diag0 = left;
+                u32 pc[PB1 ? C : 1];
                 sb_for<0, C>([&](auto K) {
                     constexpr int k = decltype(K)::value;
                     const u32 old = h[k];
-                    const u32 hn = pk_cell<j>(dprev, SA[k], SB[k], old, prev, gg);
+                    u32 hn;
+                    if constexpr (PB1) hn = pk_cell_p<j>(dprev, SA[k], SB[k], old, prev, gg, one2, two2, pc[k]);
+                    else hn = pk_cell<j>(dprev, SA[k], SB[k], old, prev, gg);
                     h[k] = hn;
                     dprev = old;
                     prev = hn;
                 });
+                if constexpr (PB1) {
+                    // byte j of a pair's word: the codes of columns j, j + 4, j + 8, j + 12 at two bits each (Horner in packed arithmetic,
+                    // halves = pairs); two v_perm_b32 separate the pairs
+                    u32 nib[4];
+                    sb_for<0, 4>([&](auto Jc) {
+                        constexpr int jc = decltype(Jc)::value;
+                        nib[jc] = pk_mad_u16_sb(pk_mad_u16_sb(pk_mad_u16_sb(pc[jc + 12], 0x00040004u, pc[jc + 8]), 0x00040004u, pc[jc + 4]), 0x00040004u, pc[jc]);
+                    });
+                    const u32 X = pk_mad_u16_sb(nib[1], 0x01000100u, nib[0]), Y = pk_mad_u16_sb(nib[3], 0x01000100u, nib[2]);
+                    const sb_v2i w = {(int)__builtin_amdgcn_perm(Y, X, 0x05040100u), (int)__builtin_amdgcn_perm(Y, X, 0x07060302u)};
+                    // the row that left the ring a step ago, expanded to bytes: output dword k = (w >> 2k) & 0x03030303
+                    const u32 m3 = 0x03030303u, dA = (u32)dw.x, dB = (u32)dw.y;
+                    const sb_v4i dsegA = {(int)(dA & m3), (int)((dA >> 2) & m3), (int)((dA >> 4) & m3), (int)((dA >> 6) & m3)};
+                    const sb_v4i dsegB = {(int)(dB & m3), (int)((dB >> 2) & m3), (int)((dB >> 4) & m3), (int)((dB >> 6) & m3)};
+                    __builtin_amdgcn_raw_buffer_store_b128(dsegA, rPA, (int)voffP, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(dsegB, rPB, (int)voffP, 0, 0);
+                    *(sb_v2i*)(ring + (u & (GS - 1)) * (64 * 8)) = w;
+                    dw = *(const sb_v2i*)(ring + ((u + dslot) & (GS - 1)) * (64 * 8));
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)0, rPA, (int)voffP0, 0, 0);     // column 0
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)0, rPB, (int)voffP0, 0, 0);
+                    if (ragged) {   // the lane that holds the matrix's last columns: byte by byte, undelayed
+#pragma unroll
+                        for (int k = 0; k < C - 1; ++k)
+                            if (!full && k < nval && !(p.debug & 1)) {
+                                const u32 off = (u32)((u - lane) * M + c0 + k);
+                                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(pc[k] & 0xffu), rPA, (int)off, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((pc[k] >> 16) & 0xffu), rPB, (int)off, 0, 0);
+                            }
+                    }
+                    voffP += pitchP; voffP0 += pitchP0;
+                }
                 if (bw) __builtin_amdgcn_raw_buffer_store_b32((int)h[C - 1], rB, lane == 63 ? 4 : (int)SB_OOB, 4 * u, 0);   // row u - 63 at index row + 64
                 // ---- arg-max: tree of row maxima, first column that holds the maximum, strict update of the lane's record
                 auto sel = [&](u32 b, u32 x, u32 y) { return pk_mad_u16(b, pk_sub_u16(y, x), x); };    // b ? y : x  (b = 0 / 1 per half)
@@ -561,10 +651,12 @@ __global__ void __launch_bounds__(256, LE4 ? 4 : 3) sw_batch_wave16(BatchParams 
         }
     }
 }
-template __global__ void sw_batch_wave16<true, true>(BatchParams);
-template __global__ void sw_batch_wave16<true, false>(BatchParams);
-template __global__ void sw_batch_wave16<false, true>(BatchParams);
-template __global__ void sw_batch_wave16<false, false>(BatchParams);
+template __global__ void sw_batch_wave16<true, true, false>(BatchParams);
+template __global__ void sw_batch_wave16<true, false, false>(BatchParams);
+template __global__ void sw_batch_wave16<false, true, false>(BatchParams);
+template __global__ void sw_batch_wave16<false, false, false>(BatchParams);
+template __global__ void sw_batch_wave16<true, true, true>(BatchParams);
+template __global__ void sw_batch_wave16<false, true, true>(BatchParams);
 
 #define SB_INST(C, PB) template __global__ void sw_batch_wave<C, PB>(BatchParams);
 SB_INST(4, 0) SB_INST(4, 1) SB_INST(4, 4) SB_INST(8, 0) SB_INST(8, 1) SB_INST(8, 4) SB_INST(16, 0) SB_INST(16, 1) SB_INST(16, 4)

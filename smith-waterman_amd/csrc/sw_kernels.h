@@ -104,8 +104,8 @@ __global__ void sw_batch_codes(const unsigned char* b, int64_t rows, int64_t b_p
                                const unsigned int* part, int npart, unsigned char* atab, int64_t npairs);
 template <int C, int PB>
 __global__ void sw_batch_wave(BatchParams p);
-template <bool LE4, bool K12>
-__global__ void sw_batch_wave16(BatchParams p);   // two pairs per wave on packed 16-bit lanes (score + exact maxPos only)
+template <bool LE4, bool K12, bool PB1>
+__global__ void sw_batch_wave16(BatchParams p);   // two pairs per wave on packed 16-bit lanes (score + exact maxPos; PB1: int8 P too)
 
 template <typename HT, int B>
 __global__ void sw_strip_scan(const unsigned char* a, const unsigned char* b, FillParams p);

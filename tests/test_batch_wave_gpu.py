@@ -17,7 +17,9 @@ def _pairs(rng, npairs, cols, rows, letters=4):
 def _check(engine, oracle, A, B, scores=(3, -3, -2), p_dtype=None, store_h=True, expect_wave=True):
     import torch
     res, H, P = engine.batch(A, B, scores=scores, store=True, p_dtype=p_dtype, store_h=store_h)
-    assert engine.get_option("last_batch_kernel") == (1 if expect_wave else 0)
+    # (an int8 P as the only matrix of pairs wider than 512 columns whose scores fit 12 bits: two pairs per wave on packed lanes)
+    packed_p = p_dtype is not None and not store_h and A.shape[1] > 512 and A.shape[0] >= 2 and scores[0] * min(A.shape[1], B.shape[1]) < 4096 and -scores[2] < 32000
+    assert engine.get_option("last_batch_kernel") == ((2 if packed_p else 1) if expect_wave else 0)
     res = res.cpu().numpy()
     for k in range(A.shape[0]):
         h, p, mp = oracle.fill(A[k], B[k], scores)
@@ -191,3 +193,67 @@ def test_packed16_keyed_argmax_up_to_12_bit_scores(engine, oracle, match, cols, 
     A[2] = np.resize(np.frombuffer(b"ACGT", np.uint8), cols); B[2] = np.resize(np.frombuffer(b"ACGT", np.uint8), rows)
     A[3] = np.resize(np.frombuffer(b"AACC", np.uint8), cols); B[3] = np.resize(np.frombuffer(b"AC", np.uint8), rows)
     _check16(engine, oracle, A, B, scores=(match, -3, -2))
+
+
+# ---- packed lanes with an int8 P (sw_batch_wave16<.., PB1>): the P codes come out of packed arithmetic, two pairs per wave ---------------
+def _check16p(engine, oracle, A, B, scores=(3, -3, -2), expect=2):
+    import torch
+    res, H, P = engine.batch(A, B, scores=scores, store=True, p_dtype=torch.int8, store_h=False)
+    assert H is None and engine.get_option("last_batch_kernel") == expect
+    res, P = res.cpu().numpy(), P.cpu().numpy()
+    for k in range(A.shape[0]):
+        h, p, mp = oracle.fill(A[k], B[k], scores)
+        assert np.array_equal(P[k].astype(np.int32), p), f"pair {k} P: first difference at {np.argwhere(P[k].astype(np.int32) != p)[:3].tolist()}"
+        assert res[k, 0] == mp and res[k, 1] == int(h.flat[mp]), f"pair {k} arg-max {res[k]} vs {mp}"
+
+
+@pytest.mark.parametrize("cols,rows,npairs", [(513, 1, 2), (600, 70, 9), (1024, 300, 8), (1000, 129, 3), (777, 64, 17), (1023, 65, 2), (1024, 1024, 5), (528, 33, 4)])
+def test_packed16_p8_shapes_even_and_odd_batches(engine, oracle, cols, rows, npairs):
+    """full and ragged last lanes (cols % 16), rows from one to more than the wave skew, an odd last pair (runs alone in both halves, stored once)"""
+    A, B = _pairs(np.random.default_rng(cols + 7 * rows), npairs, cols, rows)
+    _check16p(engine, oracle, A, B)
+
+
+@pytest.mark.parametrize("cols,rows", [(1025, 50), (1500, 300), (2500, 200)])
+def test_packed16_p8_wider_than_one_strip(engine, oracle, cols, rows):
+    A, B = _pairs(np.random.default_rng(cols), 5, cols, rows)
+    _check16p(engine, oracle, A, B)
+
+
+@pytest.mark.parametrize("letters", [1, 2, 3, 4, 5, 7, 8])
+def test_packed16_p8_alphabets(engine, oracle, letters):
+    A, B = _pairs(np.random.default_rng(letters), 6, 700, 150, letters)
+    _check16p(engine, oracle, A, B)
+
+
+@pytest.mark.parametrize("scores", [(5, -3, -4), (1, -1, -1), (2, 1, -1), (3, -3, 0), (6, -20, -7), (0, 0, 0)])
+def test_packed16_p8_scorings(engine, oracle, scores):
+    """every tie-break of the P code: a positive mismatch and a zero gap make DIAGONAL / UP / LEFT attain the maximum together"""
+    A, B = _pairs(np.random.default_rng(abs(hash(scores)) % 1000), 6, 640, 120)
+    _check16p(engine, oracle, A, B, scores=scores)
+
+
+def test_packed16_p8_ties_identical_and_disjoint_pairs_and_traceback(engine, oracle):
+    import torch
+    cols, rows = 800, 300
+    A = np.tile(np.frombuffer(b"ACGT", np.uint8), (8, cols // 4))
+    B = np.tile(np.frombuffer(b"ACGT", np.uint8), (8, rows // 4))
+    A[1], B[1] = 65, 65
+    A[2], B[2] = 65, 67
+    A[3] = np.frombuffer(b"AC", np.uint8).repeat(cols // 2)
+    B[4] = np.frombuffer(b"GT", np.uint8).repeat(rows // 2)
+    A[6], B[6] = 71, 71
+    A[7], B[7] = 84, 67
+    _check16p(engine, oracle, A, B)
+    res, H, P, paths = engine.batch(A, B, store=True, p_dtype=torch.int8, store_h=False, traceback=True, want_paths=True)
+    assert engine.get_option("last_batch_kernel") == 2
+    res, paths = res.cpu().numpy(), paths.cpu().numpy()
+    for k in range(A.shape[0]):
+        h, p, mp = oracle.fill(A[k], B[k])
+        opath = oracle.backtrack(p, mp)
+        assert res[k, 0] == mp and res[k, 2] == len(opath) and np.array_equal(paths[k, :len(opath)], opath), f"pair {k}"
+
+
+def test_packed16_p8_falls_back_above_12_bit_scores(engine, oracle):
+    A, B = _pairs(np.random.default_rng(5), 4, 1024, 900)
+    _check16p(engine, oracle, A, B, scores=(5, -3, -2), expect=1)     # 5 x 900 = 4500 > 4095: one pair per wave
