@@ -392,11 +392,14 @@ def run_batch(args, sw, eng, torch, dist, rank, world, local):
                        "device_ms_per_step": e0.elapsed_time(e1) / args.steps}}
     if wave:
         pb = (1 if args.p8 else 4) if args.store else 0
-        label = "batch kernel, packed 16-bit, score + arg-max only" if packed else ("batch kernel, int8 P stored" if pb == 1 else ("batch kernel, score + arg-max only" if pb == 0 else None))
+        if packed:
+            label = "batch kernel, packed 16-bit, int8 P stored" if pb == 1 else "batch kernel, packed 16-bit, score + arg-max only"
+        else:
+            label = "batch kernel, int8 P stored" if pb == 1 else ("batch kernel, score + arg-max only" if pb == 0 else None)
         ipstep, isrc = batch_valu_per_step(label) if label else (None, None)
         wsteps = (npairs // 2 if packed else npairs) * (rows + 64) * -(-cols // 1024)     # steps all waves together take
         line["roofline"] = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_GWIPS, "unit": "G wave-instr/s", "frac": None, "traffic": None,
-                            "kernel": "sw_batch_wave16<LE4>" if packed else f"sw_batch_wave<16,{pb}>",
+                            "kernel": f"sw_batch_wave16<LE4, K12, {'true' if pb == 1 else 'false'}>" if packed else f"sw_batch_wave<16,{pb}>",
                             "note": "integer max/add recurrence: no contraction, so no MFMA; the bound is vector issue (1 wave64 instruction per 4 clk per SIMD)"}
         if ipstep:
             ach = wsteps * ipstep / (dt / args.steps) / 1e9
@@ -404,6 +407,8 @@ def run_batch(args, sw, eng, torch, dist, rank, world, local):
         if bpc:
             hb = bpc * cells / (dt / args.steps) / 1e9
             line["roofline"]["hbm"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS, "algorithmic_bytes_per_cell": bpc}
+            if packed:   # (the packed kernel with P is bound by its P stream, not by vector issue: DESIGN.md section 9)
+                line["roofline"]["note"] += "; with P stored the packed kernel is bound by the store stream (see hbm)"
     elif bpc:
         ach = bpc * cells / (dt / args.steps) / 1e9
         line["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,

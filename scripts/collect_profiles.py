@@ -94,7 +94,8 @@ for key, wtag, ftag, kern, alg in (("16384x16384 int32 H + int32 P", "cfg2_WRITE
         print(f"{key}: WRITE {wb / 1e9:.2f} GB, FETCH (x2) {2 * fb / 1e9:.2f} GB, traffic / algorithmic = {(wb + 2 * fb) / alg:.3f}")
 # (steps: what all waves of the launch take together -- one wave per pair, or per two pairs in the packed kernel -- x 1088 steps each)
 for tag, pairs, label, kern, per_wave in (("batch_score_SQ", 20000, "packed 16-bit, score + arg-max only", "sw_batch_wave16", 2),
-                                          ("batch_score32_SQ", 20000, "score + arg-max only", "sw_batch_wave<", 1), ("batch_p8_SQ", 20000, "int8 P stored", "sw_batch_wave<", 1)):
+                                          ("batch_score32_SQ", 20000, "score + arg-max only", "sw_batch_wave<", 1), ("batch_p8_SQ", 20000, "packed 16-bit, int8 P stored", "sw_batch_wave16", 2),
+                                          ("batch_p8_32_SQ", 20000, "int8 P stored", "sw_batch_wave<", 1)):
     c = counters(tag, kern)
     if c:
         steps = pairs // per_wave * 1088

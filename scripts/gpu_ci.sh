@@ -60,6 +60,8 @@ step bench_gpus4_gloo_one_gpu 500 python bench.py --gpus 4 --backend gloo --step
 step bench_batch_100k_scoreonly 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1
 step bench_batch_100k_scoreonly_32bit 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1 --no-cpu --debug-flags 262144
 step bench_batch_100k_p8 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1 --store --p8 --no-h --no-cpu
+step bench_batch_100k_p8_32bit 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1 --store --p8 --no-h --no-cpu --debug-flags 2097152
+step bench_batch_100k_p8_no_stores 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1 --store --p8 --no-h --no-cpu --debug-flags 1
 step bench_batch_100k_p8_traceback 400 python bench.py --mode batch --pairs 100000 --steps 3 --warmup 1 --store --p8 --no-h --traceback --no-cpu
 step bench_batch_100k_old_path 400 python bench.py --mode batch --pairs 100000 --steps 1 --warmup 1 --no-cpu --debug-flags 65536
 # ---- CLI: fill + traceback timing as the reference prints them
@@ -84,6 +86,7 @@ pmc cfg3_FETCH_SIZE FETCH_SIZE --steps 2 --warmup 1 --placement-trials 1 --cols 
 pmc batch_score_SQ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --mode batch --pairs 20000 --steps 1 --warmup 1
 pmc batch_score32_SQ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --mode batch --pairs 20000 --steps 1 --warmup 1 --debug-flags 262144
 pmc batch_p8_SQ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --mode batch --pairs 20000 --steps 1 --warmup 1 --store --p8 --no-h
+pmc batch_p8_32_SQ "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" --mode batch --pairs 20000 --steps 1 --warmup 1 --store --p8 --no-h --debug-flags 2097152
 pmc batch_p8_WRITE_SIZE WRITE_SIZE --mode batch --pairs 20000 --steps 1 --warmup 1 --store --p8 --no-h
 pmc batch_p8_FETCH_SIZE FETCH_SIZE --mode batch --pairs 20000 --steps 1 --warmup 1 --store --p8 --no-h
 # ---- placement: TCC write counters of the same fill into a same-class and a different-class pair
