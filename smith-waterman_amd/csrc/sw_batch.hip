@@ -25,9 +25,6 @@ typedef unsigned int u32;
 typedef unsigned long long u64;
 
 constexpr u32 SB_OOB = 0xFFFFFF00u;
-#ifndef SB_RUN16
-#define SB_RUN16 512                       // the same for the packed kernel with P (two-bit rings: 16 KB per wave)
-#endif
 #ifndef SB_RUN
 #define SB_RUN 256                         // bytes of one row that a lane group stores with one instruction (int8 P)
 #endif      // buffer offset beyond every descriptor: the store is dropped
@@ -436,7 +433,6 @@ __device__ __forceinline__ u32 pk_cell(u32 dprev, u32 SA, u32 SB, u32 old, u32 p
 template <bool LE4, bool K12, bool PB1>
 __global__ void __launch_bounds__(256, PB1 ? 2 : (LE4 ? 4 : 3)) sw_batch_wave16(BatchParams p) {   // (LE4 score-only: 4 waves per SIMD, at most 128 VGPRs)
     constexpr int C = 16;
-    constexpr int RUN = PB1 ? SB_RUN16 : 256;   // bytes of one row that a lane group stores with one instruction
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t couple = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -456,13 +452,16 @@ __global__ void __launch_bounds__(256, PB1 ? 2 : (LE4 ? 4 : 3)) sw_batch_wave16(
     const u32 dmm = ((u32)(unsigned char)(signed char)p.match) ^ ((u32)(unsigned char)(signed char)p.mismatch);
     const u32 gg = (u32)p.ngap * 0x00010001u, one2 = 0x00010001u, sixteen2 = 0x00100010u, two2 = 0x00020002u;
     u64 kbestA = 0, kbestB = 0;
-    const int G = (rows + 64 + (PB1 ? RUN / C + 1 : 0) + 3) / 4;   // (delayed P stores drain for up to RUN / C + 1 more steps)
+    const int G = (rows + 64 + (PB1 ? 66 : 0) + 3) / 4;   // (delayed P stores drain for up to 65 more steps)
     const int pbytes = PB1 ? (int)((int64_t)(rows + 1) * M) : 0;
     const __amdgpu_buffer_rsrc_t rPA = __builtin_amdgcn_make_buffer_rsrc((void*)(PB1 ? (char*)p.P + pairA * p.hp_pstride : nullptr), 0, pbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rPB = __builtin_amdgcn_make_buffer_rsrc((void*)(PB1 ? (char*)p.P + pairB * p.hp_pstride : nullptr), 0, pairB != pairA ? pbytes : 0, 0x00020000);
     const bool ragged = (cols % C) != 0;
-    __shared__ __attribute__((aligned(16))) unsigned char sb_ring16[PB1 ? 4 * (RUN / C) * 64 * 8 : 16];   // per wave: 16 slots x 64 lanes x (4 + 4) bytes
-    unsigned char* const ring = sb_ring16 + (PB1 ? wave * (RUN / C) * 64 * 8 + lane * 8 : 0);
+    // per wave: a FIFO per lane, 63 - lane entries of (4 + 4) bytes deep -- lane l's piece of a row waits 63 - l steps, so that ALL 64 lanes store
+    // their pieces of ONE row with one instruction: 1024 contiguous bytes (2016 entries = 16 128 bytes per wave)
+    __shared__ __attribute__((aligned(16))) unsigned char sb_ring16[PB1 ? 4 * 2016 * 8 : 16];
+    const int dly = 63 - lane, flen = 8 * dly;
+    unsigned char* const fifo = sb_ring16 + (PB1 ? wave * 2016 * 8 + 8 * (63 * lane - lane * (lane - 1) / 2) : 0);
 
     for (int st = 0; st < nstrips; ++st) {
         const int c0 = st * 64 * C + lane * C + 1;
@@ -490,8 +489,7 @@ __global__ void __launch_bounds__(256, PB1 ? 2 : (LE4 ? 4 : 3)) sw_batch_wave16(
         // 256 contiguous bytes of ONE row per instruction
         const int nval = min(C, max(0, cols - c0 + 1));
         const bool full = PB1 && nval == C && !(p.debug & 1);
-        constexpr int GS = RUN / C;
-        const int dly = GS - 1 - (lane & (GS - 1)), dslot = (GS - dly) & (GS - 1);
+        int foff = 0;
         u32 voffP = full ? (u32)(-lane * M + c0) - (u32)((1 + dly) * M) : SB_OOB;
         const bool col0 = PB1 && st == 0 && lane == 0;
         u32 voffP0 = col0 ? 0u : SB_OOB;
@@ -551,10 +549,15 @@ __global__ void __launch_bounds__(256, PB1 ? 2 : (LE4 ? 4 : 3)) sw_batch_wave16(
                     const u32 m3 = 0x03030303u, dA = (u32)dw.x, dB = (u32)dw.y;
                     const sb_v4i dsegA = {(int)(dA & m3), (int)((dA >> 2) & m3), (int)((dA >> 4) & m3), (int)((dA >> 6) & m3)};
                     const sb_v4i dsegB = {(int)(dB & m3), (int)((dB >> 2) & m3), (int)((dB >> 4) & m3), (int)((dB >> 6) & m3)};
-                    __builtin_amdgcn_raw_buffer_store_b128(dsegA, rPA, (int)voffP, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(dsegB, rPB, (int)voffP, 0, 0);
-                    *(sb_v2i*)(ring + (u & (GS - 1)) * (64 * 8)) = w;
-                    dw = *(const sb_v2i*)(ring + ((u + dslot) & (GS - 1)) * (64 * 8));
+                    // (streaming: 3150-3190 GCUPS against 2890 write-back -- a row is written once and read much later, by the traceback)
+                    __builtin_amdgcn_raw_buffer_store_b128(dsegA, rPA, (int)voffP, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(dsegB, rPB, (int)voffP, 0, 2);
+                    dw = w;                                                          // (lane 63 waits for nobody)
+                    if (dly) {
+                        dw = *(const sb_v2i*)(fifo + foff);                          // what I produced 63 - lane steps ago ...
+                        *(sb_v2i*)(fifo + foff) = w;                                 // ... makes room for this step's
+                        foff = foff + 8 == flen ? 0 : foff + 8;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)0, rPA, (int)voffP0, 0, 0);     // column 0
                     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)0, rPB, (int)voffP0, 0, 0);
                     if (ragged) {   // the lane that holds the matrix's last columns: byte by byte, undelayed
