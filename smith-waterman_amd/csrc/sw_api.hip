@@ -784,8 +784,8 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
     // instead of 8).  (debug bit 18: off, A/B runs)
     const bool fits16 = npairs >= 2 && C == 16 && (int64_t)sc->match * std::min(cols, rows) < 32000 && -sc->gap < 32000 && rows < 65000 && !(c->opt_debug & 262144);
     const bool k12 = (int64_t)sc->match * std::min(cols, rows) < 4096;   // (scores of 12 bits: the arg-max runs on score * 16 + column keys)
-    // ... and with an int8 P as the only matrix (scores of 12 bits), P codes from packed arithmetic (debug bit 21: off)
-    const bool packed16 = fits16 && !d_H && (!d_P || (p_elem_bytes == 1 && k12 && !(c->opt_debug & 2097152)));
+    // ... and with an int8 P as the only matrix, P codes from packed arithmetic (debug bit 21: off)
+    const bool packed16 = fits16 && !d_H && (!d_P || (p_elem_bytes == 1 && !(c->opt_debug & 2097152)));
     for (int64_t k0 = 0; k0 < npairs; k0 += chunk) {
         const int64_t n = std::min(chunk, npairs - k0);
         hipLaunchKernelGGL(swk::sw_batch_codes, dim3((unsigned)std::min<int64_t>((per + 255) / 256, 64), (unsigned)std::min<int64_t>(n, 65535)), dim3(256), 0, stream,
@@ -812,8 +812,8 @@ static int batch_one_pair_per_wave(sw_ctx* c, const char* d_a, int64_t a_stride,
         if (packed16 && n >= 2) {
             const dim3 grid16((unsigned)(((n + 1) / 2 + 3) / 4)), block16(256);   // 4 waves = 8 pairs per workgroup
             if (d_P) {
-                if (nletters <= 4u) hipLaunchKernelGGL((swk::sw_batch_wave16<true, true, true>), grid16, block16, 0, stream, bp);
-                else hipLaunchKernelGGL((swk::sw_batch_wave16<false, true, true>), grid16, block16, 0, stream, bp);
+                if (nletters <= 4u) { if (k12) hipLaunchKernelGGL((swk::sw_batch_wave16<true, true, true>), grid16, block16, 0, stream, bp); else hipLaunchKernelGGL((swk::sw_batch_wave16<true, false, true>), grid16, block16, 0, stream, bp); }
+                else { if (k12) hipLaunchKernelGGL((swk::sw_batch_wave16<false, true, true>), grid16, block16, 0, stream, bp); else hipLaunchKernelGGL((swk::sw_batch_wave16<false, false, true>), grid16, block16, 0, stream, bp); }
             } else if (nletters <= 4u) { if (k12) hipLaunchKernelGGL((swk::sw_batch_wave16<true, true, false>), grid16, block16, 0, stream, bp); else hipLaunchKernelGGL((swk::sw_batch_wave16<true, false, false>), grid16, block16, 0, stream, bp); }
             else { if (k12) hipLaunchKernelGGL((swk::sw_batch_wave16<false, true, false>), grid16, block16, 0, stream, bp); else hipLaunchKernelGGL((swk::sw_batch_wave16<false, false, false>), grid16, block16, 0, stream, bp); }
             HIP_TRY(hipGetLastError());

@@ -660,6 +660,8 @@ template __global__ void sw_batch_wave16<false, true, false>(BatchParams);
 template __global__ void sw_batch_wave16<false, false, false>(BatchParams);
 template __global__ void sw_batch_wave16<true, true, true>(BatchParams);
 template __global__ void sw_batch_wave16<false, true, true>(BatchParams);
+template __global__ void sw_batch_wave16<true, false, true>(BatchParams);
+template __global__ void sw_batch_wave16<false, false, true>(BatchParams);
 
 #define SB_INST(C, PB) template __global__ void sw_batch_wave<C, PB>(BatchParams);
 SB_INST(4, 0) SB_INST(4, 1) SB_INST(4, 4) SB_INST(8, 0) SB_INST(8, 1) SB_INST(8, 4) SB_INST(16, 0) SB_INST(16, 1) SB_INST(16, 4)

@@ -18,7 +18,7 @@ def _check(engine, oracle, A, B, scores=(3, -3, -2), p_dtype=None, store_h=True,
     import torch
     res, H, P = engine.batch(A, B, scores=scores, store=True, p_dtype=p_dtype, store_h=store_h)
     # (an int8 P as the only matrix of pairs wider than 512 columns whose scores fit 12 bits: two pairs per wave on packed lanes)
-    packed_p = p_dtype is not None and not store_h and A.shape[1] > 512 and A.shape[0] >= 2 and scores[0] * min(A.shape[1], B.shape[1]) < 4096 and -scores[2] < 32000
+    packed_p = p_dtype is not None and not store_h and A.shape[1] > 512 and A.shape[0] >= 2 and scores[0] * min(A.shape[1], B.shape[1]) < 32000 and -scores[2] < 32000
     assert engine.get_option("last_batch_kernel") == ((2 if packed_p else 1) if expect_wave else 0)
     res = res.cpu().numpy()
     for k in range(A.shape[0]):
@@ -254,6 +254,8 @@ def test_packed16_p8_ties_identical_and_disjoint_pairs_and_traceback(engine, ora
         assert res[k, 0] == mp and res[k, 2] == len(opath) and np.array_equal(paths[k, :len(opath)], opath), f"pair {k}"
 
 
-def test_packed16_p8_falls_back_above_12_bit_scores(engine, oracle):
+def test_packed16_p8_above_12_bit_scores_and_the_15_bit_fall_back(engine, oracle):
     A, B = _pairs(np.random.default_rng(5), 4, 1024, 900)
-    _check16p(engine, oracle, A, B, scores=(5, -3, -2), expect=1)     # 5 x 900 = 4500 > 4095: one pair per wave
+    A[1], B[1] = 65, 65
+    _check16p(engine, oracle, A, B, scores=(5, -3, -2))               # 5 x 900 = 4500 > 4095: the arg-max by descent, still two pairs per wave
+    _check16p(engine, oracle, A, B, scores=(40, -3, -2), expect=1)    # 40 x 900 = 36000 > 2^15: one pair per wave
