@@ -456,11 +456,19 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             // (sw_systolic2.inc); option "s2w" forces one of the two (tests, A/B runs)
             const bool band_io = j.d_top || j.d_top_gran || j.d_bot_gran;
             int64_t W2 = 126;
-            // (measured, 126 / 110, GCUPS: int64 H 16384^2 268 / 262, 24576^2 231 / 240, 32768^2 274 / 299, 49152^2 293 / 348, 65536^2 331..352 / 387..406;
-            //  int32 H 16384^2 330 / 306, 32768^2 388 / 362, 49152^2 420 / 409, 65536^2 438 / 426, 81920^2 454 / 463: the overlap costs 14 % more strips and
-            //  a dearer consumer, the whole lines win where the stores bound the fill -- an int64 H beyond the reach of the scouts)
-            const bool wl_fmt = !band_io && cols % 2 == 0 && j.d_H && j.d_P && j.p_elem_bytes == 4 && j.stride == cols + 1;
-            if (c->opt_s2w == 110 ? (!band_io && cols % 2 == 0) : (c->opt_s2w == 0 && wl_fmt && j.h_elem_bytes == 8 && (cols - 126 + 125) / 126 + 1 > 170)) W2 = 110;
+            // Overlapping strips store whole 64-byte lines, and whole lines can be STREAMED (nt): together that is worth 1.2 - 1.5x wherever the strips
+            // do not leave room for scouts (GCUPS, strips every 126 write-back / every 110 streaming, same buffers: int32 H 21760^2 278 (tiles) / 363,
+            // 24576^2 314 (tiles) / 409, 32768^2 382 (tiles) / 481, 40000^2 385 / 540, 49152^2 403 / 595, 65536^2 436 / 624, 81920^2 474 / 559; int64 H
+            // 20480^2 264 (scouts) / 330, 24576^2 238 / 369, 32768^2 265 / 409, 49152^2 282 / 403, 65536^2 382 / 451).  Streaming PARTIAL lines is what
+            // round 2 measured as harmful; write-back whole lines are what the first version of the overlap did (+14 % for int64 H only).  Behind
+            // scouts (up to 170 strips) the 126-column geometry stays: there the chain bounds the fill and 14 % more strips cost more than the
+            // stores gain (int32 16384^2: 335 / 322) -- except for an int64 H whose 110-column strips no longer fit beside scouts (18 700 - 21 400
+            // columns), which is faster as a plain chain of overlapping strips than behind scouts.
+            const bool wl_fmt = !band_io && cols % 2 == 0 && j.d_H && j.d_P && j.p_elem_bytes == 4 && j.stride == cols + 1 &&
+                                ((uintptr_t)j.d_H & (j.h_elem_bytes == 8 ? 15u : 7u)) == 0 && ((uintptr_t)j.d_P & 7u) == 0;
+            const int64_t S126 = cols <= 126 ? 1 : (cols - 126 + 125) / 126 + 1, S110 = cols <= 126 ? 1 : (cols - 126 + 109) / 110 + 1;
+            if (c->opt_s2w == 110 ? (!band_io && cols % 2 == 0) : (c->opt_s2w == 0 && wl_fmt && (S126 > 170 || (j.h_elem_bytes == 8 && S110 > 170)))) W2 = 110;
+            const bool ov_auto = W2 == 110 && c->opt_s2w == 0;   // (the library's own choice: one launch, streaming stores)
             auto strips_of = [&](int64_t ncols) { return ncols <= 126 ? (int64_t)1 : (ncols - 126 + W2 - 1) / W2 + 1; };
             const int64_t S2all = strips_of(cols);
             // Column tiles.  Scout workgroups beside one filler per strip (sw_systolic2.inc) need 1.5 .. 2 workgroups per strip: up to ~170
@@ -471,7 +479,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             // it pays: not where the stores bound the fill anyway (int64 H at 65536^2), not for bands (their halo row arrives while they
             // run).  (debug bit 19: off)
             int64_t ntile = 1, tstrips = S2all;
-            if (S2all > 170 && base_mode && j.stride == cols + 1 && j.d_result && !(c->opt_debug & 524288)) {
+            if (S2all > 170 && base_mode && j.stride == cols + 1 && j.d_result && !ov_auto && !(c->opt_debug & 524288)) {
                 const int64_t nt = (S2all + 159) / 160, st = (S2all + nt - 1) / nt;
                 // measured (one box, GCUPS tiled / untiled): 24576^2 314 / 277, 32768^2 376 / 330, 40000^2 328 / 394, 49152^2 308 / 406 -- a tile
                 // ramps up and drains its chain with the stores idle (3.0 TB/s on average where the untiled fill of a big matrix keeps 3.3),
@@ -491,6 +499,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             p2.cols = tcols;
             p2.s2w = (int)W2;
             if (ntile > 1) p2.store_nt = c->opt_store_policy == 2 || (c->opt_store_policy == 0 && (double)tcols * (double)rows <= 6.0e8);   // (per launch, as for a matrix of the tile's size)
+            if (W2 == 110 && wl_fmt && c->opt_store_policy == 0) p2.store_nt = 1;   // (whole lines: streamed)
             p2.alpha_a = ua; p2.alpha_cols = cols;
             p2.idx_off = c0; p2.final_launch = tile + 1 == ntile ? 1 : 0;
             if (ntile > 1) {

@@ -76,21 +76,36 @@ def test_overlapping_strips_16384_streaming_checksums(overlap, oracle, swamd):
     assert np.array_equal(engine.row_checksums(out.H), st["csH"]) and np.array_equal(engine.row_checksums(out.P), st["csP"])
 
 
-def test_overlapping_strips_are_the_librarys_choice_for_a_wide_int64_h(engine, oracle):
-    """beyond the reach of the scouts (more than 170 strips) an int64 H is stored in whole lines: 200 strips of 110 columns for 22000 columns,
-    175 of 126 for an int32 H; the arg-max of a strip is looked up among the cells that strip stored (rows that end inside a block, a
-    maximum in the overlap columns)"""
+def test_overlapping_strips_are_the_librarys_choice_beyond_the_scouts(engine, oracle):
+    """more than 170 strips of 126 columns (no room for scouts): one launch of 110-column strips that stream whole lines, int32 and int64 H alike
+    (200 strips for 22000 columns); an int64 H already where its 110-column strips no longer fit beside scouts (20000 columns: 182 strips);
+    odd widths and other formats keep the 126-column geometry.  The arg-max of a strip is looked up among the cells that strip stored
+    (rows that end inside a block, a maximum in the overlap columns)"""
     import torch
     for cols, rows, seed in ((22000, 50, 12), (22000, 333, 5), (21560, 17, 3)):
         a, b = oracle.generate(cols, rows, seed)
         H, P, mp = oracle.fill(a, b)
-        out = engine.fill(a, b, h_dtype=torch.int64)
-        assert engine.get_option("last_strips2") == -(-(cols - 126) // 110) + 1
-        r = out.result()
-        assert (r["max_pos"], r["max_score"]) == (mp, int(H.flat[mp]))
-        assert np.array_equal(out.H.cpu().numpy(), H.astype(np.int64)) and np.array_equal(out.P.cpu().numpy(), P)
-        out = engine.fill(a, b)
-        assert out.result()["max_pos"] == mp   # (an int32 H of this width: column tiles of 126-column strips)
+        for kw in ({"h_dtype": torch.int64}, {}):
+            out = engine.fill(a, b, **kw)
+            assert engine.get_option("last_strips2") == -(-(cols - 126) // 110) + 1 and engine.get_option("last_tiles") == 1, kw
+            r = out.result()
+            assert (r["max_pos"], r["max_score"]) == (mp, int(H.flat[mp])), kw
+            assert np.array_equal(out.H.cpu().numpy().astype(np.int64), H.astype(np.int64)) and np.array_equal(out.P.cpu().numpy(), P), kw
+    a, b = oracle.generate(20000, 40, 2)
+    H, P, mp = oracle.fill(a, b)
+    out = engine.fill(a, b, h_dtype=torch.int64)
+    assert engine.get_option("last_strips2") == 182 and engine.get_option("last_scouts") == 0 and out.result()["max_pos"] == mp
+    assert np.array_equal(out.H.cpu().numpy(), H.astype(np.int64)) and np.array_equal(out.P.cpu().numpy(), P)
+    out = engine.fill(a, b)                                  # int32 H: 159 strips of 126 columns behind scouts
+    assert engine.get_option("last_strips2") == 159 and out.result()["max_pos"] == mp and np.array_equal(out.P.cpu().numpy(), P)
+    a, b = oracle.generate(22001, 40, 2)                     # an odd width: 126-column strips (two column tiles)
+    H, P, mp = oracle.fill(a, b)
+    out = engine.fill(a, b)
+    assert engine.get_option("last_tiles") == 2 and out.result()["max_pos"] == mp and np.array_equal(out.H.cpu().numpy(), H) and np.array_equal(out.P.cpu().numpy(), P)
+    a, b = oracle.generate(22000, 40, 2)                     # int8 P: 126-column strips
+    H, P, mp = oracle.fill(a, b)
+    out = engine.fill(a, b, p_dtype=torch.int8)
+    assert engine.get_option("last_strips2") == 175 and out.result()["max_pos"] == mp and np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
 
 
 def test_overlapping_strips_maximum_in_every_overlap_column(overlap, oracle):

@@ -7,6 +7,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def strips_every_126(engine):
+    """(split strips belong to the scouts' regime of 126-column strips; an int64 H of 167 strips would otherwise run as overlapping strips)"""
+    engine.set_option("s2w", 126)
+    yield
+    engine.set_option("s2w", 0)
+
+
 def _roles_per_xcd(engine):
     if not engine.get_option("xcd_round_robin"):
         pytest.skip("workgroups are not dealt round-robin to 8 XCDs here")

@@ -89,12 +89,12 @@ def test_more_strips_than_cus_streaming_checksums(engine, oracle, swamd):
     checksums and arg-max against the streaming oracle."""
     a, b = swamd.generate(40000, 4096, 3)
     st = oracle.fill_streaming(a, b)
-    for flags, tiles, strips in ((524288, 1, 318), (0, 2, 159)):   # untiled (debug bit 19), then as the two column tiles the library picks since round 4
-        engine.set_option("debug_flags", flags)
+    for flags, tiles, strips in ((524288, 1, 318), (0, 2, 159)):   # 126-column strips: untiled (debug bit 19), then as two column tiles
+        engine.set_option("debug_flags", flags); engine.set_option("s2w", 126)
         try:
             out = engine.fill(a, b)
         finally:
-            engine.set_option("debug_flags", 0)
+            engine.set_option("debug_flags", 0); engine.set_option("s2w", 0)
         assert engine.get_option("last_tiles") == tiles and engine.get_option("last_strips2") == strips
         r = out.result()
         assert r["max_pos"] == st["max_pos"] and r["max_score"] == st["max_score"]

@@ -44,16 +44,20 @@ def test_xcd_layout_limits(engine, oracle):
         a, b = oracle.generate(126 * strips, 64, 7)
         check_against_oracle(engine, oracle, a, b)
         assert engine.get_option("last_xcd_mode") == want, f"{strips} strips"
-    # 200 strips: two column tiles of 100 strips since round 4, each dealt per XCD; untiled (debug bit 19) the plain classic chain
+    # 200 strips of 126 columns: two column tiles of 100 strips, each dealt per XCD; untiled (debug bit 19) the plain classic chain
     a, b = oracle.generate(126 * 200, 64, 7)
-    check_against_oracle(engine, oracle, a, b)
-    assert engine.get_option("last_tiles") == 2 and engine.get_option("last_xcd_mode") == 1
-    engine.set_option("debug_flags", 524288)
+    engine.set_option("s2w", 126)
     try:
+        check_against_oracle(engine, oracle, a, b)
+        assert engine.get_option("last_tiles") == 2 and engine.get_option("last_xcd_mode") == 1
+        engine.set_option("debug_flags", 524288)
         check_against_oracle(engine, oracle, a, b)
         assert engine.get_option("last_tiles") == 1 and engine.get_option("last_xcd_mode") == 0
     finally:
-        engine.set_option("debug_flags", 0)
+        engine.set_option("debug_flags", 0); engine.set_option("s2w", 0)
+    # the library's own choice there: one launch of overlapping strips (229 of them), no scouts
+    check_against_oracle(engine, oracle, a, b)
+    assert engine.get_option("last_tiles") == 1 and engine.get_option("last_strips2") == -(-(126 * 200 - 126) // 110) + 1
 
 
 @pytest.mark.parametrize("mode", ["p8", "h64", "p8_only", "score_only"])
