@@ -290,7 +290,8 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       kernel (whole-matrix or band fills of one pair, any number of rows; csrc/sw_systolic2.inc) takes 4..7 from
  *                       this option (0: 7 behind scout workgroups, else 5 up to ~3.5e8 cells, 6 above) and runs 9 minus that many
  *                       importer waves
- *   "store_policy"      systolic H/P stores: 0 by problem size, 1 write-back, 2 streaming (nt)
+ *   "store_policy"      systolic H/P stores: 0 by problem size and strip geometry (streaming up to 6e8 cells and wherever whole lines are stored),
+ *                       1 write-back, 2 streaming (nt)
  *   "importers"         systolic, one strip per workgroup: waves polling the left neighbour's edge column, besides the one that
  *                       always does (0: 4 up to ~3.5e8 cells, 2 above; at most what 12 waves per workgroup leave)
  *   "xcd_order"         systolic: 1 = neighbouring strip groups run on the same XCD
@@ -304,7 +305,8 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       with SW_ETIMEOUT (default 20000)
  *   "s2w"               two-column kernel: strips every 126 columns, or every 110 -- 126 wide, overlapping by 16 columns, so that every
  *                       64-byte line of a matrix row lies inside one strip and is stored whole, by one instruction;
- *                       0: the library chooses (110 for an int64 H with an int32 P beyond ~21 000 columns), 126 / 110 force one
+ *                       0: the library chooses (110, with streaming stores, for matrices of even width with int32 P and both matrices written that
+ *                       are too wide for scout workgroups: more than ~21 500 columns, 18 700 with an int64 H), 126 / 110 force one
  *   "split_blk", "split_from"   two-column kernel behind scouts: from strip `split_from` on, the strip's scout writes the matrix
  *                       blocks from `split_blk` on itself (0: the library chooses)
  *   "placement_budget_ms"  sw_alloc_outputs: how long the search for an H / P pair in different classes of the HBM may take at worst (default 1500; 2-5 ms on memory that needs no wiping)
