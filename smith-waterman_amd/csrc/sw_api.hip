@@ -537,7 +537,8 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 // measured (same buffers, classic against dealt per XCD): 24576^2 -1 %, 32768^2 -0.4 %, 65536^2 int32 +0.3 %, int64 H +2.3 %,
                 // 262144 x 32768 with int8 P +4.4 %: the classic hand-off is not the trip through memory (the polls of a filler queue behind
                 // its own H / P stores in the CU), so the gain is small and only where a workgroup runs several strips
-                const bool xcd_chain_pays = S2 >= 384;
+                // (with overlapping strips and streaming stores the dealing per XCD costs instead: 65536^2 int64 H 9.52 against 8.59 ms, int32 7.00 / 6.89, 24576^2 1.60 / 1.48)
+                const bool xcd_chain_pays = S2 >= 384 && W2 != 110;
                 if (scouts && c->xcd_round_robin && avail >= 256 && S2 >= 16 && !(c->opt_debug & 8388608)) {
                     bool fits = true;
                     int wg = 0, dbl = 0;
@@ -1112,6 +1113,41 @@ static int alloc_outputs_probed(sw_ctx* c, size_t hbytes, size_t pbytes, void** 
         }
         if (k.ratio < accept) { if (gib) c->place_spacer_gib = gib; break; }
         if (big && cands.size() >= 5) break;   // (... and the best of five)
+    }
+    // Matrices of many GiB span classes themselves, and so does every candidate: where none of them is good, P is allocated with up to 32 GiB of
+    // slack and SLID inside its allocation in steps of 4 GiB -- the classes are regions of 8 .. 120 GiB, so the slide changes which parts of H and
+    // P meet -- and the best offset is kept (the slack stays allocated while the pair lives: a few per cent of a 288 GB part, for a pair of tens
+    // of GiB whose fills are ~25 % faster for it).  Only while the budget covers the worst case of that allocation.
+    if (big && rc == SW_OK && best >= 0 && cands[best].ratio >= accept) {
+        size_t fr = 0, tot = 0;
+        size_t slack = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > pbytes + (24ull << 30)) slack = std::min<size_t>(32ull << 30, (fr - pbytes - (16ull << 30)) & ~((4ull << 30) - 1));
+        const double worst_ms = 40.0 * (double)((pbytes + slack) >> 30);
+        if (slack >= (8ull << 30) && elapsed_ms() + worst_ms <= (double)c->opt_place_budget_ms) {
+            void* blk = nullptr;
+            if (hipMalloc(&blk, pbytes + slack + phase) == hipSuccess) {
+                float bratio = cands[best].ratio; void* bP = nullptr;
+                for (size_t off = 0; off <= slack && rc == SW_OK; off += (4ull << 30)) {
+                    char* q = (char*)blk + off;
+                    const uintptr_t want = ((uintptr_t)H + (2u << 20)) % phase;
+                    q += (want + phase - ((uintptr_t)q % phase)) % phase;
+                    float r = 0.f, ms = 0.f;
+                    rc = sw_place_pair_ratio(H, hbytes, q, pbytes, &r, &ms);
+                    if (debug) fprintf(stderr, "sw_alloc_outputs: slide %zu GiB: ratio %.3f, %.1f ms so far\n", off >> 30, r, elapsed_ms());
+                    if (rc == SW_OK && r < bratio) { bratio = r; bP = q; }
+                    if (r < accept) break;
+                }
+                if (rc == SW_OK && bP) {
+                    Cand k = {blk, bP, bratio};
+                    cands.push_back(k);
+                    best = (int)cands.size() - 1;
+                } else {
+                    (void)hipFree(blk);
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
     }
     for (int i = 0; i < (int)cands.size(); ++i)
         if ((i != best || rc != SW_OK) && cands[i].base) (void)hipFree(cands[i].base);
