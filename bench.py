@@ -221,6 +221,7 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
         # the C-ABI allocator: candidate placements classified by its two-stream store probe (or, --placement-trials N, tried with real
         # fills), outside the timed region and before anything else touches the memory
         eng.set_option("placement_budget_ms", 20000)   # (setup, outside the timed region: the pair is filled into many times)
+        eng.set_option("placement_hold_gib", 48)        # (... and may hold slack beside P where the box's free memory is all of one class)
         t_alloc = time.perf_counter()
         out, placement_ms = eng.alloc_outputs(d_a, d_b, cols, rows, h_dtype, p_dtype, trials=args.placement_trials)
         t_alloc = time.perf_counter() - t_alloc
@@ -280,6 +281,7 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
                                       ("candidates classified by a two-stream store probe, no trial fills)" if args.placement_trials <= 0 else "placement chosen by trial fills)"))
                                      if placement_ms is not None else "plain first allocation",
                    "placement_probe_ms" if args.placement_trials <= 0 else "placement_trials_ms": placement_ms, "sw_alloc_outputs_ms": t_alloc * 1e3,
+                   "placement_held_gib": eng.get_option("last_placement_held_gib"),
                    "placement_ratio": eng.get_option("last_placement_ratio_x1000") / 1000.0 if placement_ms is not None else None,
                    "value_first_allocation": value_first, "value_first_allocation_is": "the same fill into a plain pair of torch allocations (two back-to-back hipMallocs: usually one class)",
                    "preheat_fills": nheat,

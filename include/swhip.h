@@ -309,6 +309,10 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       are too wide for scout workgroups: more than ~21 500 columns, 18 700 with an int64 H), 126 / 110 force one
  *   "split_blk", "split_from"   two-column kernel behind scouts: from strip `split_from` on, the strip's scout writes the matrix
  *                       blocks from `split_blk` on itself (0: the library chooses)
+ *   "placement_hold_gib"  sw_alloc_outputs: where no candidate pair lies in two classes of the HBM (the usual case once most of a device's memory
+ *                       has been in use: the driver then hands out the little clean memory it has, all of one class), P may be allocated with up
+ *                       to this many GiB of slack and slid inside its own allocation to where the probe is good; the slack stays allocated
+ *                       while the pair lives (sw_get_option "last_placement_held_gib").  Default 0; pairs of many GiB take up to 32 by themselves
  *   "placement_budget_ms"  sw_alloc_outputs: how long the search for an H / P pair in different classes of the HBM may take at worst (default 1500; 2-5 ms on memory that needs no wiping)
  *   "max_blocks"        cap of the resident grid (0 = all CUs); concurrent band launches partition the CUs with it
  *   "waves_per_block", "debug_flags", "debug_buf", "batch_lds"   development aids (debug_flags 131072: no scout workgroups,

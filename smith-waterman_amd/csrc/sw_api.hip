@@ -56,8 +56,10 @@ struct sw_ctx {
     unsigned char* d_priv = nullptr; size_t priv_cap = 0;   // ... and every workgroup's own padded copy of b + letter codes
     int64_t opt_s2w = 0;                // two-column kernel: strips every 126 or 110 columns (overlapping strips, whole-line stores); 0: the library chooses
     int64_t opt_split_blk = 0, opt_split_from = 0;   // split strips: forced split block / first strip (0: chosen by the library; tests)
+    int64_t opt_place_hold_gib = 0;     // sw_alloc_outputs: GiB a pair of small matrices may hold beside itself where no plain candidate is good (0: none)
     int64_t opt_place_budget_ms = 1500; // sw_alloc_outputs: time the search for a P in another class of the HBM may take
     int place_spacer_gib = 0;           // ... the spacer that led to one last time
+    int64_t last_place_held_gib = 0;
     float last_place_ratio = 0.f;       // ... two-stream / one-stream time of the pair handed out last (~1.3-1.45: different classes, ~2: one class)
     bool key_dirty = false;             // d_key was left non-zero by a launch that does not re-arm it (everything but the one-launch fill)
     bool last_fused = false;            // the last launch_fill reports by itself (no sw_finalize behind it)
@@ -165,6 +167,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "batch_lds")) { c->opt_batch_lds = v < 0 ? 0 : v; return SW_OK; }
     if (!strcmp(name, "band_wait_ms")) { c->opt_band_wait_ms = v > 0 ? v : 20000; return SW_OK; }
     if (!strcmp(name, "placement_budget_ms")) { c->opt_place_budget_ms = v > 0 ? v : 1500; return SW_OK; }
+    if (!strcmp(name, "placement_hold_gib")) { c->opt_place_hold_gib = v < 0 ? 0 : (v > 128 ? 128 : v); return SW_OK; }
     if (!strcmp(name, "s2w")) { if (v != 0 && v != 126 && v != 110) return SW_EINVAL; c->opt_s2w = v; return SW_OK; }
     if (!strcmp(name, "split_blk")) { c->opt_split_blk = v > 0 ? v : 0; return SW_OK; }
     if (!strcmp(name, "split_from")) { c->opt_split_from = v > 0 ? v : 0; return SW_OK; }
@@ -203,6 +206,8 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "xcd_round_robin")) return c->xcd_round_robin ? 1 : 0;
     if (!strcmp(name, "last_batch_kernel")) return c->last_batch_kernel;
     if (!strcmp(name, "placement_budget_ms")) return c->opt_place_budget_ms;
+    if (!strcmp(name, "placement_hold_gib")) return c->opt_place_hold_gib;
+    if (!strcmp(name, "last_placement_held_gib")) return c->last_place_held_gib;
     if (!strcmp(name, "last_placement_ratio_x1000")) return (int64_t)(c->last_place_ratio * 1000.f);
     return -1;
 }
@@ -1114,14 +1119,21 @@ static int alloc_outputs_probed(sw_ctx* c, size_t hbytes, size_t pbytes, void** 
         if (k.ratio < accept) { if (gib) c->place_spacer_gib = gib; break; }
         if (big && cands.size() >= 5) break;   // (... and the best of five)
     }
-    // Matrices of many GiB span classes themselves, and so does every candidate: where none of them is good, P is allocated with up to 32 GiB of
-    // slack and SLID inside its allocation in steps of 4 GiB -- the classes are regions of 8 .. 120 GiB, so the slide changes which parts of H and
-    // P meet -- and the best offset is kept (the slack stays allocated while the pair lives: a few per cent of a 288 GB part, for a pair of tens
-    // of GiB whose fills are ~25 % faster for it).  Only while the budget covers the worst case of that allocation.
-    if (big && rc == SW_OK && best >= 0 && cands[best].ratio >= accept) {
+    // The slide.  Where no candidate is good -- matrices of many GiB span classes themselves, and so does every candidate; on a box whose
+    // memory was in use before, the driver hands out the little clean memory it has, all of one class, whatever the spacers (seen: twelve
+    // candidates in a row at ratio 2.0) -- P is allocated with slack and SLID inside its own allocation in steps of 4 GiB: one allocation is
+    // backed by whatever memory there is, dirty regions of the other classes included, and the classes are regions of 8 .. 120 GiB, so the
+    // slide changes which parts of H and P meet.  The best offset is kept; the slack stays allocated while the pair lives.  Many-GiB pairs
+    // take up to 32 GiB of slack by themselves (a few per cent of a 288 GB part for fills that are ~25 % faster); smaller pairs only what
+    // option "placement_hold_gib" allows (default 0: bench.py, which fills thousands of times into the pair, allows 48).  Only while the
+    // budget covers the worst case of that allocation.
+    c->last_place_held_gib = 0;
+    const size_t hold_max = big ? (32ull << 30) : ((size_t)c->opt_place_hold_gib << 30);
+    const bool force_slide = getenv("SW_PLACE_FORCE_SLIDE") != nullptr;   // (tests: take the slide whatever the candidates were)
+    if (hold_max >= (8ull << 30) && rc == SW_OK && best >= 0 && (cands[best].ratio >= accept || force_slide)) {
         size_t fr = 0, tot = 0;
         size_t slack = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > pbytes + (24ull << 30)) slack = std::min<size_t>(32ull << 30, (fr - pbytes - (16ull << 30)) & ~((4ull << 30) - 1));
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > pbytes + (24ull << 30)) slack = std::min<size_t>(hold_max, (fr - pbytes - (16ull << 30)) & ~((4ull << 30) - 1));
         const double worst_ms = 40.0 * (double)((pbytes + slack) >> 30);
         if (slack >= (8ull << 30) && elapsed_ms() + worst_ms <= (double)c->opt_place_budget_ms) {
             void* blk = nullptr;
@@ -1134,13 +1146,14 @@ static int alloc_outputs_probed(sw_ctx* c, size_t hbytes, size_t pbytes, void** 
                     float r = 0.f, ms = 0.f;
                     rc = sw_place_pair_ratio(H, hbytes, q, pbytes, &r, &ms);
                     if (debug) fprintf(stderr, "sw_alloc_outputs: slide %zu GiB: ratio %.3f, %.1f ms so far\n", off >> 30, r, elapsed_ms());
-                    if (rc == SW_OK && r < bratio) { bratio = r; bP = q; }
-                    if (r < accept) break;
+                    if (rc == SW_OK && (r < bratio || (force_slide && !bP))) { bratio = r; bP = q; }
+                    if (r < accept && !force_slide) break;
                 }
                 if (rc == SW_OK && bP) {
                     Cand k = {blk, bP, bratio};
                     cands.push_back(k);
                     best = (int)cands.size() - 1;
+                    c->last_place_held_gib = (int64_t)(slack >> 30);
                 } else {
                     (void)hipFree(blk);
                 }

@@ -51,3 +51,33 @@ def test_dropping_a_pair_returns_its_memory(engine, swamd):
     out, _ = engine.alloc_outputs(d_a, d_b, n, n)
     out.free()                                  # explicit release
     assert out.H is None and torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+
+
+def test_slide_inside_a_larger_allocation(engine, oracle, swamd, monkeypatch):
+    """where no candidate pair is good, P is slid inside an allocation with slack (option placement_hold_gib; forced here): the pair is
+    usable, reports what it holds, and gives everything back when dropped"""
+    import torch
+    n = 12288
+    if torch.cuda.mem_get_info()[0] < (60 << 30):
+        pytest.skip("needs 60 GB of free HBM")
+    a, b = swamd.generate(n, n, 3)
+    d_a, _ = engine.to_device(a)
+    d_b, _ = engine.to_device(b)
+    engine.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    monkeypatch.setenv("SW_PLACE_FORCE_SLIDE", "1")
+    engine.set_option("placement_hold_gib", 16); engine.set_option("placement_budget_ms", 20000)
+    try:
+        out, ms = engine.alloc_outputs(d_a, d_b, n, n)
+    finally:
+        engine.set_option("placement_hold_gib", 0); engine.set_option("placement_budget_ms", 0)
+    assert engine.get_option("last_placement_held_gib") == 16
+    assert free0 - torch.cuda.mem_get_info()[0] >= (16 << 30) + 2 * (n + 1) * (n + 1) * 4
+    engine.fill_into(out, d_a, d_b)
+    engine.synchronize()
+    st = oracle.fill_streaming(a, b)
+    r = out.result()
+    assert (r["max_pos"], r["max_score"]) == (st["max_pos"], st["max_score"])
+    assert np.array_equal(engine.row_checksums(out.H), st["csH"]) and np.array_equal(engine.row_checksums(out.P), st["csP"])
+    out.free()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
