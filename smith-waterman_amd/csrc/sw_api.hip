@@ -469,10 +469,10 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             // scouts (up to 170 strips) the 126-column geometry stays: there the chain bounds the fill and 14 % more strips cost more than the
             // stores gain (int32 16384^2: 335 / 322) -- except for an int64 H whose 110-column strips no longer fit beside scouts (18 700 - 21 400
             // columns), which is faster as a plain chain of overlapping strips than behind scouts.
-            const bool wl_fmt = !band_io && cols % 2 == 0 && j.d_H && j.d_P && j.p_elem_bytes == 4 && j.stride == cols + 1 &&
+            const bool wl_fmt = !band_io && j.d_H && j.d_P && j.p_elem_bytes == 4 && j.stride == cols + 1 &&
                                 ((uintptr_t)j.d_H & (j.h_elem_bytes == 8 ? 15u : 7u)) == 0 && ((uintptr_t)j.d_P & 7u) == 0;
             const int64_t S126 = cols <= 126 ? 1 : (cols - 126 + 125) / 126 + 1, S110 = cols <= 126 ? 1 : (cols - 126 + 109) / 110 + 1;
-            if (c->opt_s2w == 110 ? (!band_io && cols % 2 == 0) : (c->opt_s2w == 0 && wl_fmt && (S126 > 170 || (j.h_elem_bytes == 8 && S110 > 170)))) W2 = 110;
+            if (c->opt_s2w == 110 ? (!band_io && (cols % 2 == 0 || wl_fmt)) : (c->opt_s2w == 0 && wl_fmt && (S126 > 170 || (j.h_elem_bytes == 8 && S110 > 170)))) W2 = 110;
             const bool ov_auto = W2 == 110 && c->opt_s2w == 0;   // (the library's own choice: one launch, streaming stores)
             auto strips_of = [&](int64_t ncols) { return ncols <= 126 ? (int64_t)1 : (ncols - 126 + W2 - 1) / W2 + 1; };
             const int64_t S2all = strips_of(cols);

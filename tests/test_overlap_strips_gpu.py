@@ -15,7 +15,8 @@ def overlap(engine):
 
 
 @pytest.mark.parametrize("cols,rows,seed", [(126, 40, 1), (236, 33, 2), (5040, 333, 3), (4400, 272, 4), (16500, 144, 5), (1000, 1000, 6), (346, 17, 7), (14410, 64, 8),
-                                            (2, 16, 9), (110, 16, 10), (112, 100, 11), (20000, 50, 12)])
+                                            (2, 16, 9), (110, 16, 10), (112, 100, 11), (20000, 50, 12),
+                                            (5041, 333, 13), (4401, 100, 14), (16501, 144, 15), (347, 17, 16), (237, 33, 17), (1001, 1000, 18), (127, 40, 19), (20001, 50, 20)])
 def test_overlapping_strips_match_the_oracle(overlap, oracle, cols, rows, seed):
     import torch
     engine = overlap
@@ -23,7 +24,8 @@ def test_overlapping_strips_match_the_oracle(overlap, oracle, cols, rows, seed):
     H, P, mp = oracle.fill(a, b)
     for kw in ({}, {"p_dtype": torch.int8}, {"h_dtype": torch.int64}, {"want_h": False}, {"want_h": False, "want_p": False}, {"want_p": False}):
         out = engine.fill(a, b, **kw)
-        if engine.get_option("last_tiles") == 1:
+        if engine.get_option("last_tiles") == 1 and (cols % 2 == 0 or kw == {}):
+            # (an odd width runs on the two-column kernel only with int32 H + int32 P -- and then with whole-line stores, every row shifted)
             assert engine.get_option("last_strips2") == (1 if cols <= 126 else -(-(cols - 126) // 110) + 1), kw
         r = out.result()
         assert (r["max_pos"], r["max_score"]) == (mp, int(H.flat[mp])), kw
@@ -98,10 +100,13 @@ def test_overlapping_strips_are_the_librarys_choice_beyond_the_scouts(engine, or
     assert np.array_equal(out.H.cpu().numpy(), H.astype(np.int64)) and np.array_equal(out.P.cpu().numpy(), P)
     out = engine.fill(a, b)                                  # int32 H: 159 strips of 126 columns behind scouts
     assert engine.get_option("last_strips2") == 159 and out.result()["max_pos"] == mp and np.array_equal(out.P.cpu().numpy(), P)
-    a, b = oracle.generate(22001, 40, 2)                     # an odd width: 126-column strips (two column tiles)
+    a, b = oracle.generate(22001, 40, 2)                     # an odd width: every row stores shifted pairs
     H, P, mp = oracle.fill(a, b)
     out = engine.fill(a, b)
-    assert engine.get_option("last_tiles") == 2 and out.result()["max_pos"] == mp and np.array_equal(out.H.cpu().numpy(), H) and np.array_equal(out.P.cpu().numpy(), P)
+    assert engine.get_option("last_tiles") == 1 and engine.get_option("last_strips2") == 200 and out.result()["max_pos"] == mp
+    assert np.array_equal(out.H.cpu().numpy(), H) and np.array_equal(out.P.cpu().numpy(), P)
+    out = engine.fill(a, b, p_dtype=torch.int8)             # ... an odd width with int8 P: the one-column kernel
+    assert engine.get_option("last_strips2") == 0 and out.result()["max_pos"] == mp and np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
     a, b = oracle.generate(22000, 40, 2)                     # int8 P: 126-column strips
     H, P, mp = oracle.fill(a, b)
     out = engine.fill(a, b, p_dtype=torch.int8)
