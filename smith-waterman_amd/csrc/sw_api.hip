@@ -340,6 +340,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         if (NC == 0) NC = (NS == 1) ? (chain_bound ? 4 : 6) : 4;
         const int importers = c->opt_importers > 0 ? (int)c->opt_importers : (chain_bound && NC <= 4 ? 4 : 2);
         if (NS == 1 && NC > 7) NC = 7;         // nine waves off the producer's SIMD: at most 7 consumers + exporter + importer
+        if (NS == 1 && NC == 5) NC = 4;        // (the one-column kernel has no five-consumer form: option "consumers" = 5 is for the two-column kernel)
         // padded copies of b per problem: [front | b | tail]; front covers the fast producers' phi (< strips) + 63 lanes
         // (+ one 16-step block: the perm producer's first score window ends at step 0)
         const int64_t bfront = ((S + 64 + 32 + 127) / 128) * 128;
@@ -614,7 +615,8 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
                 p2.result = j.d_result; p2.skip_row0 = (j.d_top || j.d_top_gran) ? 1 : 0;
                 // consumer waves (+ 9 - nc2 importers).  Behind scouts a filler is never the one a hand-off waits for: two importers do, and seven
                 // consumers keep more stores in flight (16384^2 -1.5 %, 12288^2 -2.5 %, 20480^2 +-0 against five)
-                const int nc2 = c->opt_consumers == 0 ? (scouts ? 7 : (chain_bound ? 5 : 6)) : (int)std::min<int64_t>(7, c->opt_consumers);
+                // (overlapping strips, whose consumers are dearer: seven as well -- 32768^2 485 against 453-466 GCUPS, 65536^2 633 / 607, int64 H 502 / 495)
+                const int nc2 = c->opt_consumers == 0 ? ((scouts || W2 == 110) ? 7 : (chain_bound ? 5 : 6)) : (int)std::min<int64_t>(7, c->opt_consumers);
                 auto launch2 = [&](auto nc, auto ov) { hipLaunchKernelGGL((swk::sw_systolic2<decltype(nc)::value, decltype(ov)::value>), dim3(grid2), dim3(768), 0, stream, ua_t, ub, p2); };
                 auto launch_nc = [&](auto ov) {
                     if (nc2 == 7) launch2(std::integral_constant<int, 7>{}, ov);
