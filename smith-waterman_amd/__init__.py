@@ -560,6 +560,18 @@ def _hip_d2h(arr: np.ndarray, dptr: int):
     arr.view(np.uint8).reshape(-1)[:] = t.cpu().numpy()
 
 
+def fill_host(engine: "Engine", a, b, scores=DEFAULT_SCORES):
+    """sw_fill_host: the drop-in for the reference's fill loop on HOST buffers -- what `main` owns after its two
+    callocs (serial_smithW.c:96-103) goes in, H, P and maxPos come back in the reference's layout.  Returns dict with H, P, max_pos, max_score."""
+    a, b = _as_seq(a).copy(), _as_seq(b).copy()
+    cols, rows = len(a), len(b)
+    H = np.zeros((rows + 1, cols + 1), np.int32)
+    P = np.zeros((rows + 1, cols + 1), np.int32)
+    sc, r = _Scores(*scores), _Result()
+    _check(lib().sw_fill_host(engine._h, a.ctypes.data, cols, b.ctypes.data, rows, ctypes.byref(sc), H.ctypes.data, P.ctypes.data, ctypes.byref(r)))
+    return {"H": H, "P": P, "max_pos": r.max_pos, "max_score": r.max_score}
+
+
 def align_auto(a, b, scores=DEFAULT_SCORES, engine: "Engine | None" = None, devices=None, multi_min_cells: int = 0):
     """sw_align_auto: host fill for tiny problems, the GPU of `engine` otherwise; host traceback.  With `devices` (a list of GPU ids,
     ids may repeat) sw_align_auto_multi: host / one GPU / row bands over all of them, chosen by size.  Returns dict like

@@ -207,3 +207,14 @@ def test_align_auto_picks_host_or_gpu(engine, oracle, swamd):
         r = swamd.align_auto(a, b, engine=engine)
         assert r["used_gpu"] == want_gpu
         assert np.array_equal(r["H"], H) and np.array_equal(r["P"], P) and r["max_pos"] == mp and r["path_len"] == len(path)
+
+
+@pytest.mark.parametrize("cols,rows,seed", [(8, 9, 1), (1000, 700, 2), (4097, 333, 3), (22000, 60, 4), (22001, 33, 5), (126 * 171, 17, 6)])
+def test_fill_host_is_the_reference_fill_on_host_buffers(engine, oracle, swamd, cols, rows, seed):
+    """sw_fill_host, the entry point of INTEGRATION.md section 2: host sequences in, H / P / maxPos in the reference's layout out -- narrow,
+    odd and wide shapes (the wide ones run as overlapping strips with streaming stores, the copy-out follows on two streams)"""
+    a, b = oracle.generate(cols, rows, seed)
+    H, P, mp = oracle.fill(a, b)
+    r = swamd.fill_host(engine, a, b)
+    assert (r["max_pos"], r["max_score"]) == (mp, int(H.flat[mp]))
+    assert np.array_equal(r["H"], H) and np.array_equal(r["P"], P)
