@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "sw_kernels.h"
 
@@ -972,6 +973,20 @@ int sw_fill_host(sw_ctx* c, const char* a, int64_t cols, const char* b, int64_t 
     // fill).  A pageable destination goes through the runtime's staging buffers at a fraction of that: pin the caller's matrices for the
     // duration of the copies where the platform allows it, and run the two copies on two streams.
     if (rc == SW_OK && (H || P)) {
+        // Matrices fresh from calloc (what the reference's main hands over, serial_smithW.c:96-103) have no pages yet: whoever writes them first
+        // pays 2.1 GB of page faults at 16384^2 -- one thread ~80 ms.  Every byte is about to be overwritten, so the pages are touched first,
+        // by several threads (one write per 4 KiB page).
+        if (cells * 4 >= (64u << 20)) {
+            const unsigned nt = std::max(1u, std::min(std::min(16u, std::thread::hardware_concurrency()), (unsigned)(cells * 4 / (128u << 20))));
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t)
+                th.emplace_back([=]() {
+                    const size_t n = cells * 4, lo = n / nt * t, hi = t + 1 == nt ? n : n / nt * (t + 1);
+                    for (int32_t* M : {H, P})
+                        if (M) for (size_t o = (lo + 4095) & ~(size_t)4095; o < hi; o += 4096) ((volatile char*)M)[o] = 0;
+                });
+            for (auto& x : th) x.join();
+        }
         const bool pinH = H && cells * 4 >= (64u << 20) && hipHostRegister(H, cells * 4, hipHostRegisterDefault) == hipSuccess;
         const bool pinP = P && cells * 4 >= (64u << 20) && hipHostRegister(P, cells * 4, hipHostRegisterDefault) == hipSuccess;
         (void)hipGetLastError();
