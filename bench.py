@@ -5,7 +5,7 @@ One "step" = one full DP fill (H and P matrices + arg-max) of ONE cols x rows ra
 already resident in HBM.
 
   N = 1   BASELINE config[1]: 16384 x 16384, int32 H + int32 P on one GPU.  `value` is measured on output buffers from
-          the C-ABI allocator sw_alloc_outputs (what a C caller gets); `config.value_first_allocation` is the same fill
+          the C-ABI allocator sw_alloc_outputs (what a C caller gets); `config.value_first_allocation` / `value_foreign_pair` are the same fill
           into a plain first allocation.
   N > 1   BASELINE config[3]: ONE 262144 x 262144 matrix cut into N row bands, one per rank (strong scaling: the work
           is fixed, N varies), band-resident launches with the halo rows forwarded rank to rank over RCCL.  550 GB of
@@ -242,16 +242,24 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
         out.H.fill_(0)
     f1.record(); torch.cuda.synchronize()
     fill_gbs = 5 * out.H.numel() * out.H.element_size() / (f0.elapsed_time(f1) * 1e-3) / 1e9
-    # the same fill into a plain pair of torch allocations (a handful of launches: `value_first_allocation`)
+    # the same fill into plain pairs (a handful of launches each): `value_first_allocation` -- two back-to-back allocations through the C-ABI
+    # (sw_alloc_outputs with trials = 1: no search, but the library probes the pair once and picks the strip geometry by the class it
+    # finds) -- and `value_foreign_pair` -- two torch allocations the library knows nothing about
     if args.placement_trials == 1:
         first = out
     else:
-        first = eng.alloc(cols, rows, h_dtype, p_dtype)
+        first, _ = eng.alloc_outputs(d_a, d_b, cols, rows, h_dtype, p_dtype, trials=1)
+    first_ratio = eng.get_option("last_placement_ratio_x1000") / 1000 if first is not out else None
     dt_first, ms_first = timed(first, max(3, args.steps // 4), 2)
     value_first = world * len(ms_first) * cols * rows / dt_first / 1e9
+    first_strips = int(eng.get_option("last_strips2")) or eng.get_option("last_strips")
     if first is not out:
-        del first
-        torch.cuda.empty_cache()
+        first.free()
+    foreign = eng.alloc(cols, rows, h_dtype, p_dtype)
+    dt_foreign, ms_foreign = timed(foreign, max(3, args.steps // 4), 2)
+    value_foreign = world * len(ms_foreign) * cols * rows / dt_foreign / 1e9
+    del foreign
+    torch.cuda.empty_cache()
     dt, kern_ms = timed(out, args.steps, args.warmup)
     res = out.result()
     tau_ns, lag_ns, shader_ghz, chain_extra = chain_stamps(sw, eng, torch, d_a, d_b, out, cols, rows) if args.engine == 0 else (0.0, 0.0, None, {})
@@ -283,7 +291,9 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
                    "placement_probe_ms" if args.placement_trials <= 0 else "placement_trials_ms": placement_ms, "sw_alloc_outputs_ms": t_alloc * 1e3,
                    "placement_held_gib": eng.get_option("last_placement_held_gib"),
                    "placement_ratio": eng.get_option("last_placement_ratio_x1000") / 1000.0 if placement_ms is not None else None,
-                   "value_first_allocation": value_first, "value_first_allocation_is": "the same fill into a plain pair of torch allocations (two back-to-back hipMallocs: usually one class)",
+                   "value_first_allocation": value_first, "value_first_allocation_is": "the same fill into a plain pair from the C-ABI (sw_alloc_outputs, trials = 1: two back-to-back hipMallocs, usually one class of the HBM; the library probes the pair once and fills a one-class pair with overlapping strips)",
+                   "first_allocation_probe_ratio": first_ratio, "first_allocation_strips": first_strips,
+                   "value_foreign_pair": value_foreign, "value_foreign_pair_is": "the same fill into two torch allocations (not probed: 126-column strips whatever their class)",
                    "preheat_fills": nheat,
                    "clocks_before": clocks0, "clocks_after": clocks1, "shader_clock_ghz_in_kernel": shader_ghz,
                    "ms_first_allocation": sum(ms_first) / len(ms_first)},

@@ -81,3 +81,35 @@ def test_slide_inside_a_larger_allocation(engine, oracle, swamd, monkeypatch):
     assert np.array_equal(engine.row_checksums(out.H), st["csH"]) and np.array_equal(engine.row_checksums(out.P), st["csP"])
     out.free()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+
+
+def test_a_pair_in_one_class_is_filled_with_overlapping_strips(engine, oracle, swamd):
+    """sw_alloc_outputs with trials = 1 hands out a plain pair and probes it once; a fill into a pair that lies in ONE class of the HBM
+    (ratio ~2: the usual outcome) runs on overlapping strips that stream whole lines, a pair in two classes keeps the 126-column strips.
+    Either way the matrices are the oracle's."""
+    import torch
+    n = 16384
+    if torch.cuda.mem_get_info()[0] < (40 << 30):
+        pytest.skip("needs 40 GB of free HBM")
+    a, b = swamd.generate(n, n, 1)
+    d_a, _ = engine.to_device(a)
+    d_b, _ = engine.to_device(b)
+    st = oracle.fill_streaming(a, b)
+    seen, keep = set(), []
+    for _ in range(6):
+        out, _ = engine.alloc_outputs(d_a, d_b, n, n, trials=1)
+        ratio = engine.get_option("last_placement_ratio_x1000") / 1000
+        engine.fill_into(out, d_a, d_b)
+        engine.synchronize()
+        strips = engine.get_option("last_strips2")
+        assert strips == (149 if ratio >= 1.7 else 131), (ratio, strips)
+        if strips not in seen:
+            r = out.result()
+            assert (r["max_pos"], r["max_score"]) == (st["max_pos"], st["max_score"])
+            assert np.array_equal(engine.row_checksums(out.H), st["csH"]) and np.array_equal(engine.row_checksums(out.P), st["csP"])
+        seen.add(strips)
+        keep.append(out)                        # (the next plain pair lands elsewhere)
+        if len(seen) == 2:
+            break
+    for out in keep:
+        out.free()
