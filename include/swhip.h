@@ -309,6 +309,10 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       are too wide for scout workgroups: more than ~21 500 columns, 18 700 with an int64 H), 126 / 110 force one
  *   "split_blk", "split_from"   two-column kernel behind scouts: from strip `split_from` on, the strip's scout writes the matrix
  *                       blocks from `split_blk` on itself (0: the library chooses)
+ *   "probe_foreign_pairs"  1: an H / P pair the library did not allocate is probed once, at its first fill (big int32 fills behind scouts only): the
+ *                       probe WRITES both buffers -- the fill overwrites them anyway -- and synchronises the stream (~0.3 ms); a pair found to
+ *                       lie in one class of the HBM is then filled with overlapping strips (16384^2: ~310 instead of ~235 GCUPS).  Default 0
+ *                       (pairs from sw_alloc_outputs are known without it)
  *   "placement_hold_gib"  sw_alloc_outputs: where no candidate pair lies in two classes of the HBM (the usual case once most of a device's memory
  *                       has been in use: the driver then hands out the little clean memory it has, all of one class), P may be allocated with up
  *                       to this many GiB of slack and slid inside its own allocation to where the probe is good; the slack stays allocated

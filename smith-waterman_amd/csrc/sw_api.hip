@@ -57,6 +57,7 @@ struct sw_ctx {
     unsigned char* d_priv = nullptr; size_t priv_cap = 0;   // ... and every workgroup's own padded copy of b + letter codes
     int64_t opt_s2w = 0;                // two-column kernel: strips every 126 or 110 columns (overlapping strips, whole-line stores); 0: the library chooses
     int64_t opt_split_blk = 0, opt_split_from = 0;   // split strips: forced split block / first strip (0: chosen by the library; tests)
+    int64_t opt_probe_foreign = 0;      // fills: probe an output pair the library did not allocate once, at its first fill (the probe writes and synchronises)
     int64_t opt_place_hold_gib = 0;     // sw_alloc_outputs: GiB a pair of small matrices may hold beside itself where no plain candidate is good (0: none)
     int64_t opt_place_budget_ms = 1500; // sw_alloc_outputs: time the search for a P in another class of the HBM may take
     int place_spacer_gib = 0;           // ... the spacer that led to one last time
@@ -170,6 +171,7 @@ int sw_set_option(sw_ctx* c, const char* name, int64_t v) {
     if (!strcmp(name, "band_wait_ms")) { c->opt_band_wait_ms = v > 0 ? v : 20000; return SW_OK; }
     if (!strcmp(name, "placement_budget_ms")) { c->opt_place_budget_ms = v > 0 ? v : 1500; return SW_OK; }
     if (!strcmp(name, "placement_hold_gib")) { c->opt_place_hold_gib = v < 0 ? 0 : (v > 128 ? 128 : v); return SW_OK; }
+    if (!strcmp(name, "probe_foreign_pairs")) { c->opt_probe_foreign = v ? 1 : 0; return SW_OK; }
     if (!strcmp(name, "s2w")) { if (v != 0 && v != 126 && v != 110) return SW_EINVAL; c->opt_s2w = v; return SW_OK; }
     if (!strcmp(name, "split_blk")) { c->opt_split_blk = v > 0 ? v : 0; return SW_OK; }
     if (!strcmp(name, "split_from")) { c->opt_split_from = v > 0 ? v : 0; return SW_OK; }
@@ -209,6 +211,7 @@ int64_t sw_get_option(sw_ctx* c, const char* name) {
     if (!strcmp(name, "last_batch_kernel")) return c->last_batch_kernel;
     if (!strcmp(name, "placement_budget_ms")) return c->opt_place_budget_ms;
     if (!strcmp(name, "placement_hold_gib")) return c->opt_place_hold_gib;
+    if (!strcmp(name, "probe_foreign_pairs")) return c->opt_probe_foreign;
     if (!strcmp(name, "last_placement_held_gib")) return c->last_place_held_gib;
     if (!strcmp(name, "last_placement_ratio_x1000")) return (int64_t)(c->last_place_ratio * 1000.f);
     return -1;
@@ -479,7 +482,19 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             // plain pair) is slowed much less when its lines are streamed whole: 16384^2 307 against 232 GCUPS with 126-column strips -- 7 % behind a
             // pair in two classes instead of 30 %.  (Pairs the library did not allocate are not probed -- the probe writes -- and keep 126.)
             bool one_class = false;
-            if (j.d_P && (double)cols * (double)rows >= 2.0e8) { auto it = c->pair_ratio.find(j.d_P); one_class = it != c->pair_ratio.end() && it->second >= 1.7f; }
+            if (j.d_P && (double)cols * (double)rows >= 2.0e8) {
+                auto it = c->pair_ratio.find(j.d_P);
+                if (it == c->pair_ratio.end() && c->opt_probe_foreign && c->opt_s2w == 0 && wl_fmt && S126 <= 170 && !j.reserve_only) {
+                    // option "probe_foreign_pairs": a pair the library did not allocate is probed once, at its first fill -- the probe WRITES both
+                    // buffers (this fill overwrites them anyway) and synchronises the stream (~0.3 ms); remembered by the address of P (at most 64)
+                    float r = 0.f, ms = 0.f;
+                    if (c->pair_ratio.size() >= 64) c->pair_ratio.clear();
+                    if (hipStreamSynchronize(stream) == hipSuccess &&
+                        sw_place_pair_ratio(j.d_H, (size_t)(cols + 1) * (size_t)(rows + 1) * (size_t)j.h_elem_bytes, j.d_P, (size_t)(cols + 1) * (size_t)(rows + 1) * 4, &r, &ms) == SW_OK)
+                        it = c->pair_ratio.emplace(j.d_P, r).first;
+                }
+                one_class = it != c->pair_ratio.end() && it->second >= 1.7f;
+            }
             if (c->opt_s2w == 110 ? (!band_io && (cols % 2 == 0 || wl_fmt)) : (c->opt_s2w == 0 && wl_fmt && (S126 > 170 || (j.h_elem_bytes == 8 && S110 > 170) || one_class))) W2 = 110;
             const bool ov_auto = W2 == 110 && c->opt_s2w == 0;   // (the library's own choice: one launch, streaming stores)
             auto strips_of = [&](int64_t ncols) { return ncols <= 126 ? (int64_t)1 : (ncols - 126 + W2 - 1) / W2 + 1; };

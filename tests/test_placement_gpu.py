@@ -113,3 +113,27 @@ def test_a_pair_in_one_class_is_filled_with_overlapping_strips(engine, oracle, s
             break
     for out in keep:
         out.free()
+
+
+def test_probe_foreign_pairs_option(engine, oracle, swamd):
+    """buffers the library did not allocate (torch tensors) are probed once, at their first fill, when the option says so: one-class pairs run
+    on overlapping strips; the results do not depend on it"""
+    import torch
+    n = 16384
+    a, b = swamd.generate(n, n, 1)
+    d_a, _ = engine.to_device(a)
+    d_b, _ = engine.to_device(b)
+    st = oracle.fill_streaming(a, b)
+    out = engine.alloc(n, n)
+    engine.fill_into(out, d_a, d_b); engine.synchronize()
+    assert engine.get_option("last_strips2") == 131             # unknown pair: 126-column strips
+    engine.set_option("probe_foreign_pairs", 1)
+    try:
+        for _ in range(2):
+            engine.fill_into(out, d_a, d_b); engine.synchronize()
+            assert engine.get_option("last_strips2") in (131, 149)
+        r = out.result()
+        assert (r["max_pos"], r["max_score"]) == (st["max_pos"], st["max_score"])
+        assert np.array_equal(engine.row_checksums(out.H), st["csH"]) and np.array_equal(engine.row_checksums(out.P), st["csP"])
+    finally:
+        engine.set_option("probe_foreign_pairs", 0)
