@@ -107,9 +107,12 @@ def test_overlapping_strips_are_the_librarys_choice_beyond_the_scouts(engine, or
     assert np.array_equal(out.H.cpu().numpy(), H) and np.array_equal(out.P.cpu().numpy(), P)
     out = engine.fill(a, b, p_dtype=torch.int8)             # ... an odd width with int8 P: the one-column kernel
     assert engine.get_option("last_strips2") == 0 and out.result()["max_pos"] == mp and np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
-    a, b = oracle.generate(22000, 40, 2)                     # int8 P: 126-column strips
+    a, b = oracle.generate(22000, 40, 2)                     # int32 H + int8 P: whole lines of H, the P bytes as ever
     H, P, mp = oracle.fill(a, b)
     out = engine.fill(a, b, p_dtype=torch.int8)
+    assert engine.get_option("last_strips2") == 200 and out.result()["max_pos"] == mp
+    assert np.array_equal(out.H.cpu().numpy(), H) and np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
+    out = engine.fill(a, b, p_dtype=torch.int8, want_h=False)   # P only: 126-column strips
     assert engine.get_option("last_strips2") == 175 and out.result()["max_pos"] == mp and np.array_equal(out.P.cpu().numpy().astype(np.int32), P)
 
 
