@@ -49,6 +49,7 @@ step bench_i32_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 6553
 step bench_i32_64k_untiled 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --debug-flags 524288
 # ---- config 3
 step bench_h64_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64
+step bench_p8_64k 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --p8
 step bench_h64_64k_strips_every_126 400 python bench.py --steps 3 --warmup 1 --no-cpu --cols 65536 --rows 65536 --h64 --s2w 126
 step bench_i32_16k_strips_every_110 200 python bench.py --steps 20 --warmup 3 --no-cpu --s2w 110
 # ---- config 4 on one GPU: the per-rank shape of the 8-GPU run, the whole matrix P-only, two ranks rehearsing over gloo
