@@ -401,7 +401,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
         // (... and int32 H + int8 P beyond the reach of the scouts: the H of overlapping strips goes out in streamed whole lines -- 65536^2 597 GCUPS
         //  against 429 on the one-column kernel and 494 with 126-column strips)
         const bool pays = (j.d_H && j.d_P && j.p_elem_bytes == 4) || (j.d_H && j.h_elem_bytes == 8) || est_chain >= (j.d_H ? 0.5 : 2.0) * est_hbm || (c->opt_debug & 32768) ||
-                          (j.d_H && j.d_P && j.h_elem_bytes == 4 && j.p_elem_bytes == 1 && cols % 2 == 0 && cols > 126 * 170);
+                          (j.d_H && j.h_elem_bytes == 4 && (!j.d_P || j.p_elem_bytes == 1) && cols % 2 == 0 && cols > 126 * 170);
         int per_cu2 = 0;
         bool two_cols = pays && perm_ok && c->opt_strips_per_group == 0 && (c->opt_consumers == 0 || c->opt_consumers >= 4) && j.npairs == 1 &&
                               !j.d_left && !j.d_right && j.stride == cols + 1 && (rows % 16 == 0 || !j.d_bot_gran) && rows >= 1 && cols >= 1 &&   // (a band's last row leaves from a full block)
@@ -478,7 +478,7 @@ static int launch_fill(sw_ctx* c, const sw_scores* sc, const FillJob& j, hipStre
             // scouts (up to 170 strips) the 126-column geometry stays: there the chain bounds the fill and 14 % more strips cost more than the
             // stores gain (int32 16384^2: 335 / 322) -- except for an int64 H whose 110-column strips no longer fit beside scouts (18 700 - 21 400
             // columns), which is faster as a plain chain of overlapping strips than behind scouts.
-            const bool wl_fmt = !band_io && j.d_H && j.d_P && (j.p_elem_bytes == 4 || (j.h_elem_bytes == 4 && cols % 2 == 0)) && j.stride == cols + 1 &&
+            const bool wl_fmt = !band_io && j.d_H && (!j.d_P || j.p_elem_bytes == 4 || (j.h_elem_bytes == 4 && cols % 2 == 0)) && (j.d_P || cols % 2 == 0) && j.stride == cols + 1 &&
                                 ((uintptr_t)j.d_H & (j.h_elem_bytes == 8 ? 15u : 7u)) == 0 && ((uintptr_t)j.d_P & 7u) == 0;
             const int64_t S126 = cols <= 126 ? 1 : (cols - 126 + 125) / 126 + 1, S110 = cols <= 126 ? 1 : (cols - 126 + 109) / 110 + 1;
             // A pair that lies in ONE class of the HBM (the allocator's probe said so: its search ran out of budget, or the caller asked for a
