@@ -225,6 +225,9 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
         t_alloc = time.perf_counter()
         out, placement_ms = eng.alloc_outputs(d_a, d_b, cols, rows, h_dtype, p_dtype, trials=args.placement_trials)
         t_alloc = time.perf_counter() - t_alloc
+    # (read now: the plain pair of the `value_first_allocation` leg below is probed too)
+    out_ratio = eng.get_option("last_placement_ratio_x1000") / 1000 if args.placement_trials != 1 else None
+    out_held = eng.get_option("last_placement_held_gib") if args.placement_trials != 1 else 0
     # pre-heat: at least --preheat seconds of back-to-back fills before anything is timed (a freshly leased GPU idles at
     # 95 MHz; the W warm-up steps of the contract follow, inside timed()) -- into the buffers of the timed region, so that a
     # kernel trace of this command averages launches of ONE kind
@@ -250,13 +253,13 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
     else:
         first, _ = eng.alloc_outputs(d_a, d_b, cols, rows, h_dtype, p_dtype, trials=1)
     first_ratio = eng.get_option("last_placement_ratio_x1000") / 1000 if first is not out else None
-    dt_first, ms_first = timed(first, max(3, args.steps // 4), 2)
+    dt_first, ms_first = timed(first, max(3, args.steps // 4), 4)
     value_first = world * len(ms_first) * cols * rows / dt_first / 1e9
     first_strips = int(eng.get_option("last_strips2")) or eng.get_option("last_strips")
     if first is not out:
         first.free()
     foreign = eng.alloc(cols, rows, h_dtype, p_dtype)
-    dt_foreign, ms_foreign = timed(foreign, max(3, args.steps // 4), 2)
+    dt_foreign, ms_foreign = timed(foreign, max(3, args.steps // 4), 4)
     value_foreign = world * len(ms_foreign) * cols * rows / dt_foreign / 1e9
     del foreign
     torch.cuda.empty_cache()
@@ -289,8 +292,8 @@ def run_pair(args, sw, eng, torch, dist, rank, world, local):
                                       ("candidates classified by a two-stream store probe, no trial fills)" if args.placement_trials <= 0 else "placement chosen by trial fills)"))
                                      if placement_ms is not None else "plain first allocation",
                    "placement_probe_ms" if args.placement_trials <= 0 else "placement_trials_ms": placement_ms, "sw_alloc_outputs_ms": t_alloc * 1e3,
-                   "placement_held_gib": eng.get_option("last_placement_held_gib"),
-                   "placement_ratio": eng.get_option("last_placement_ratio_x1000") / 1000.0 if placement_ms is not None else None,
+                   "placement_held_gib": out_held,
+                   "placement_ratio": out_ratio if placement_ms is not None else None,
                    "value_first_allocation": value_first, "value_first_allocation_is": "the same fill into a plain pair from the C-ABI (sw_alloc_outputs, trials = 1: two back-to-back hipMallocs, usually one class of the HBM; the library probes the pair once and fills a one-class pair with overlapping strips)",
                    "first_allocation_probe_ratio": first_ratio, "first_allocation_strips": first_strips,
                    "value_foreign_pair": value_foreign, "value_foreign_pair_is": "the same fill into two torch allocations (not probed: 126-column strips whatever their class)",
