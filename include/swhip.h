@@ -305,7 +305,8 @@ int sw_synchronize(sw_ctx* ctx, void* stream);   /* waits for `stream`; reports 
  *                       with SW_ETIMEOUT (default 20000)
  *   "s2w"               two-column kernel: strips every 126 columns, or every 110 -- 126 wide, overlapping by 16 columns, so that every
  *                       64-byte line of a matrix row lies inside one strip and is stored whole, by one instruction;
- *                       0: the library chooses (110, with streaming stores, for matrices with int32 P and both matrices written -- an int64 H: even widths -- that
+ *                       0: the library chooses (110, with streaming stores, for matrices with H written and P int32, absent, or int8 beside an int32 H -- even
+ *                       widths but for int32 H + int32 P -- that
  *                       are too wide for scout workgroups: more than ~21 500 columns, 18 700 with an int64 H), 126 / 110 force one
  *   "split_blk", "split_from"   two-column kernel behind scouts: from strip `split_from` on, the strip's scout writes the matrix
  *                       blocks from `split_blk` on itself (0: the library chooses)
